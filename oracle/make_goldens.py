@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own classes (build container only).
+
+    python oracle/make_goldens.py [--only NAME]
+
+Test infrastructure.  The reference (/root/reference) cannot travel to the GPU box, so the vectors
+it produces here are committed as small fixtures together with this script.  The driver below
+composes the reference objects in the order of ``MAIN/OOPAOEnv/OOPAOEnv.py:93-385`` (set_params) with
+the Shack-Hartmann construction of ``MAIN/OOPAOEnv/OOPAOEnvRazor.py:234-238`` and replays
+``OOPAOEnv.py:485-536`` (step) with the reference's objects doing all the arithmetic; nothing here
+re-implements physics.  See ``oracle/_ref_loader.py`` for the import shims and for the one stage
+(the skimage sub-pixel warp) that is not pinned by the reference.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+sys.path.insert(0, REPO)
+
+from oracle import _ref_loader as RL  # noqa: E402
+from oracle import ao_oracle as O      # noqa: E402   (only: Zernike basis for geometries without an M2C file)
+
+GOLD = os.path.join(REPO, "tests", "golden")
+MANUAL_M2C = "/root/reference/drl4ao/MAIN_CODE/OOPAOEnv/manual_m2c.npy"
+
+CASES = {
+    # name: geometry + atmosphere + loop
+    "tiny_sh": dict(R=24, nsub=4, D=1.6, r0=0.13, L0=30.0, ws=[10.0], wd=[72.0], frac=[1.0], alt=[0.0],
+                    n_modes=8, steps=40, seeds=[0, 17], gain=0.5, full_every=1),
+    "tiny_fastwind": dict(R=24, nsub=4, D=1.6, r0=0.13, L0=30.0, ws=[50.0], wd=[200.0], frac=[1.0], alt=[0.0],
+                          n_modes=8, steps=12, seeds=[3], gain=0.4, full_every=1),
+    "tiny_3layer": dict(R=24, nsub=4, D=1.6, r0=0.13, L0=30.0, ws=[10.0, 12.0, 11.0], wd=[0.0, 72.0, 144.0],
+                        frac=[0.45 / 0.65, 0.1 / 0.65, 0.1 / 0.65], alt=[0.0, 0.0, 0.0],
+                        n_modes=8, steps=30, seeds=[17], gain=0.5, full_every=1),
+    "small_sh": dict(R=48, nsub=8, D=3.2, r0=0.13, L0=30.0, ws=[10.0], wd=[72.0], frac=[1.0], alt=[0.0],
+                     n_modes=20, steps=50, seeds=[0, 17], gain=0.5, full_every=10),
+    "c2_sh": dict(R=120, nsub=20, D=8.0, r0=0.13, L0=30.0, ws=[10.0], wd=[72.0], frac=[1.0], alt=[0.0],
+                  n_modes=50, steps=20, seeds=[17], gain=0.5, full_every=10, m2c_file=True),
+}
+
+
+def build(ref, c):
+    """Reference objects, composed as OOPAOEnv.set_params does (with an SH WFS)."""
+    with RL.quiet():
+        tel = ref.Telescope(resolution=c["R"], diameter=c["D"], samplingTime=1 / 500, centralObstruction=0,
+                            display_optical_path=False, fov=0)
+        ngs = ref.Source(optBand="I", magnitude=8, coordinates=[0, 0])
+        ngs * tel
+        atm = ref.Atmosphere(telescope=tel, r0=c["r0"], L0=c["L0"], windSpeed=list(c["ws"]),
+                             fractionalR0=list(c["frac"]), windDirection=list(c["wd"]), altitude=list(c["alt"]))
+        atm.initializeAtmosphere(tel)
+        atm.update()
+        nAct = c["nsub"] + 1
+        dm = ref.DeformableMirror(telescope=tel, nSubap=c["nsub"], mechCoupling=0.35, coordinates=None,
+                                  pitch=tel.D / nAct)
+        tel.isPaired = False
+        tel.resetOPD()
+        wfs = ref.ShackHartmann(telescope=tel, nSubap=c["nsub"], lightRatio=0.5, is_geometric=False,
+                                shannon_sampling=True)
+        tel * wfs
+        if c.get("m2c_file"):
+            m2c = np.load(MANUAL_M2C)[:, :c["n_modes"]]                    # OOPAOEnv.py:260
+        else:
+            # OOPAOEnv.py:258 / OOPAOEnvRazor.py:261 with the Noll basis restated in the oracle (aotools absent)
+            Z = O.zernike_modes(tel.pupil > 0, tel.D, c["n_modes"])
+            m2c = np.linalg.pinv(np.squeeze(dm.modes[tel.pupilLogical, :])) @ Z
+        tel - atm
+        calib = ref.InteractionMatrix(ngs=ngs, atm=atm, tel=tel, dm=dm, wfs=wfs, M2C=np.eye(dm.nValidAct),
+                                      stroke=ngs.wavelength / 16, nMeasurements=6, noise="off", display=False,
+                                      single_pass=True)
+        vault = ref.CalibrationVault(calib.D @ m2c)
+        tel.resetOPD()
+        dm.coefs = 0
+        ngs * tel * dm * wfs
+        atm.generateNewPhaseScreen(seed=10)
+        tel + atm
+    recon = m2c @ vault.M
+    F = m2c @ np.linalg.pinv(m2c)
+    dm_mask = np.reshape(dm.validAct, (nAct, nAct))
+    xv, yv = np.nonzero(dm_mask)
+    return dict(tel=tel, ngs=ngs, atm=atm, dm=dm, wfs=wfs, m2c=m2c, D=calib.D, recon=recon, F=F,
+                xvalid=xv, yvalid=yv, nAct=nAct)
+
+
+def run_episode(env, c, seed):
+    """mbrl.py:49-55 prologue + integrator closed loop through OOPAOEnv.step arithmetic."""
+    tel, atm, dm, wfs = env["tel"], env["atm"], env["dm"], env["wfs"]
+    nAct, xv, yv, recon = env["nAct"], env["xvalid"], env["yvalid"], env["recon"]
+    leak = 0.99
+
+    def vec_to_img(v):
+        img = np.zeros((nAct, nAct))
+        img[xv, yv] = v
+        return img
+
+    with RL.quiet():
+        atm.generateNewPhaseScreen(seed)
+        dm.coefs = 0
+        tel * dm * wfs
+    dm_prev = dm.coefs.copy()
+    obs0 = vec_to_img(-np.matmul(recon, wfs.signal)) * 1e6          # reset_soft
+    T = c["steps"]
+    R = c["R"]
+    out = dict(obs0=obs0, mapShift0=np.stack([getattr(atm, f"layer_{i + 1}").mapShift.copy() for i in range(atm.nLayer)]),
+               signal0=wfs.signal.copy(),
+               actions=np.zeros((T, nAct, nAct), np.float32), obs=np.zeros((T, nAct, nAct)),
+               reward=np.zeros(T), strehl=np.zeros(T), total=np.zeros(T), residual=np.zeros(T),
+               signal=np.zeros((T, wfs.nSignal)), coefs=np.zeros((T, dm.nValidAct)),
+               buff=np.zeros((T, atm.nLayer, 2)), full_steps=[], opd_atm=[], opd_res=[], frame=[], mapShift=[])
+    obs = obs0
+    for i in range(T):
+        action = np.float32(c["gain"] * np.float32(obs))             # TorchWrapper: f32 obs, f32 action
+        out["actions"][i] = action
+        a = action[xv, yv] * 1e-6                                    # img_to_vec(action)*1e-6   :491
+        with RL.quiet():
+            atm.update()                                             # :494
+        total = np.std(tel.OPD[np.where(tel.pupil > 0)]) * 1e9       # :497
+        opd_atm = tel.OPD.copy()
+        with RL.quiet():
+            tel * dm * wfs                                           # :503
+        dm.coefs = (dm_prev * leak) + a                              # :508
+        dm_prev = dm.coefs.copy()
+        obs = vec_to_img(-np.matmul(recon, wfs.signal)) * 1e6        # :517-518
+        out["obs"][i] = obs
+        out["reward"][i] = -1 * np.linalg.norm(obs)                  # :536
+        out["strehl"][i] = np.exp(-np.var(tel.src.phase[np.where(tel.pupil == 1)]))   # :554-555
+        out["total"][i] = total
+        out["residual"][i] = np.std(tel.OPD[np.where(tel.pupil > 0)]) * 1e9           # :522
+        out["signal"][i] = wfs.signal
+        out["coefs"][i] = dm.coefs
+        for l in range(atm.nLayer):
+            out["buff"][i, l] = getattr(atm, f"layer_{l + 1}").buff
+        if i % c["full_every"] == 0 or i == T - 1:
+            out["full_steps"].append(i)
+            out["opd_atm"].append(opd_atm)
+            out["opd_res"].append(tel.OPD.copy())
+            out["frame"].append(wfs.cam.frame.copy())
+            out["mapShift"].append(np.stack([getattr(atm, f"layer_{l + 1}").mapShift.copy() for l in range(atm.nLayer)]))
+    for k in ("opd_atm", "opd_res", "frame", "mapShift", "full_steps"):
+        out[k] = np.asarray(out[k])
+    assert opd_atm.shape == (R, R)
+    return out
+
+
+def make_case(ref, name):
+    c = CASES[name]
+    env = build(ref, c)
+    tel, atm, dm, wfs = env["tel"], env["atm"], env["dm"], env["wfs"]
+    L1 = atm.layer_1
+    consts = dict(
+        cfg_R=c["R"], cfg_nsub=c["nsub"], cfg_D=c["D"], cfg_r0=c["r0"], cfg_L0=c["L0"],
+        cfg_ws=np.array(c["ws"]), cfg_wd=np.array(c["wd"]), cfg_frac=np.array(c["frac"]), cfg_alt=np.array(c["alt"]),
+        cfg_gain=c["gain"], cfg_n_modes=c["n_modes"], cfg_seeds=np.array(c["seeds"]),
+        pupil=tel.pupil.astype(bool), wavelength=env["ngs"].wavelength, nPhoton=env["ngs"].nPhoton,
+        validAct=np.asarray(dm.validAct, bool), valid_subap=np.asarray(wfs.valid_subapertures, bool),
+        reference_slopes_maps=wfs.reference_slopes_maps, slopes_units=wfs.slopes_units,
+        m2c=env["m2c"], imat=env["D"], recon=env["recon"], F=env["F"],
+        xvalid=env["xvalid"], yvalid=env["yvalid"])
+    if c["R"] <= 48:
+        consts.update(A=L1.A, B=L1.B, modes=dm.modes)
+    else:
+        # large constants: probes + moments instead of the full arrays
+        rs = np.random.RandomState(123)
+        pz = rs.randn(L1.A.shape[1])
+        px = rs.randn(L1.B.shape[1])
+        pc = rs.randn(dm.nValidAct)
+        consts.update(A_probe_in=pz, A_probe_out=L1.A @ pz, B_probe_in=px, B_probe_out=L1.B @ px,
+                      A_fro=np.linalg.norm(L1.A), B_fro=np.linalg.norm(L1.B), A_shape=np.array(L1.A.shape),
+                      modes_probe_in=pc, modes_probe_out=dm.modes @ pc, modes_fro=np.linalg.norm(dm.modes))
+    out = dict(consts)
+    if c["R"] > 48:
+        out.pop("F")                       # derived from the m2c input alone; keep the fixture small
+    for seed in c["seeds"]:
+        ep = run_episode(env, c, seed)
+        if c["R"] > 48:
+            ep.pop("mapShift")
+        for k, v in ep.items():
+            out[f"s{seed}_{k}"] = v
+    path = os.path.join(GOLD, f"{name}.npz")
+    np.savez_compressed(path, **out)
+    s0 = c["seeds"][0]
+    print(f"{name}: wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)  "
+          f"nValidAct={dm.nValidAct} nSignal={wfs.nSignal} "
+          f"strehl_last={out['s%d_strehl' % s0][-1]:.4f} res_last={out['s%d_residual' % s0][-1]:.1f} nm")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    ref = RL.load()
+    for name in CASES:
+        if args.only and name != args.only:
+            continue
+        make_case(ref, name)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,89 @@
+"""CPU: the NumPy oracle against the vectors the reference itself produced (tests/golden/*.npz).
+
+The goldens come from ``oracle/make_goldens.py`` (reference classes executed in the build container).
+Tolerances are float64 re-ordering noise only; the replayed actions are the recorded float32 actions, so
+closed-loop chaos cannot mask a discrepancy.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ao_oracle as O
+
+CASES = ["tiny_sh", "tiny_fastwind", "tiny_3layer", "small_sh", "c2_sh"]
+
+
+def _env_from_golden(g):
+    return O.OracleEnv(resolution=int(g["cfg_R"]), diameter=float(g["cfg_D"]), n_subap=int(g["cfg_nsub"]),
+                       r0=float(g["cfg_r0"]), L0=float(g["cfg_L0"]), windSpeed=list(g["cfg_ws"]),
+                       windDirection=list(g["cfg_wd"]), fractionalR0=list(g["cfg_frac"]),
+                       altitude=list(g["cfg_alt"]), m2c=g["m2c"], n_modes=int(g["cfg_n_modes"]))
+
+
+@pytest.fixture(scope="module", params=CASES)
+def case(request, golden_dir):
+    g = np.load(os.path.join(golden_dir, request.param + ".npz"))
+    return request.param, g, _env_from_golden(g)
+
+
+def test_constants(case):
+    name, g, env = case
+    assert np.array_equal(env.pupil, g["pupil"])
+    assert env.wavelength == float(g["wavelength"]) and env.nPhoton == float(g["nPhoton"])
+    assert np.array_equal(env.dm_mask.reshape(-1), g["validAct"])
+    assert np.array_equal(env.wfs.valid_2d, g["valid_subap"])
+    assert np.array_equal(env.xvalid, g["xvalid"]) and np.array_equal(env.yvalid, g["yvalid"])
+    np.testing.assert_allclose(env.wfs.reference_slopes_maps, g["reference_slopes_maps"], atol=1e-13)
+    np.testing.assert_allclose(env.wfs.slopes_units, float(g["slopes_units"]), rtol=1e-11)
+    lay = env.atm.layers[0]
+    if "A" in g:
+        np.testing.assert_allclose(lay.A, g["A"], atol=1e-12)
+        np.testing.assert_allclose(lay.B, g["B"], atol=1e-12)
+        np.testing.assert_allclose(env.dm_modes, g["modes"], atol=1e-15)
+    else:
+        np.testing.assert_allclose(lay.A @ g["A_probe_in"], g["A_probe_out"], atol=1e-10)
+        np.testing.assert_allclose(lay.B @ g["B_probe_in"], g["B_probe_out"], atol=1e-10)
+        np.testing.assert_allclose(np.linalg.norm(lay.A), float(g["A_fro"]), rtol=1e-12)
+        np.testing.assert_allclose(env.dm_modes @ g["modes_probe_in"], g["modes_probe_out"], atol=1e-12)
+    # separable DM factors reproduce the dense influence matrix
+    R = env.R
+    sep = np.einsum("yi,xj->yxij", env.gy, env.gx).reshape(R * R, -1)[:, env.dm_mask.reshape(-1)]
+    np.testing.assert_allclose(sep, env.dm_modes, atol=5e-16)
+
+
+def test_calibration(case):
+    name, g, env = case
+    scale = np.abs(g["imat"]).max()
+    np.testing.assert_allclose(env.imat, g["imat"], atol=1e-12 * scale)
+    np.testing.assert_allclose(env.reconstructor, g["recon"], atol=1e-9 * np.abs(g["recon"]).max())
+    if "F" in g:
+        np.testing.assert_allclose(env.F, g["F"], atol=1e-12)
+
+
+def test_closed_loop_replay(case):
+    name, g, env = case
+    for seed in g["cfg_seeds"]:
+        p = f"s{int(seed)}_"
+        env.new_episode(int(seed))
+        np.testing.assert_allclose(env.atm.layers[0].mapShift, g[p + "mapShift0"][0], atol=1e-12)
+        np.testing.assert_allclose(env.reset_soft(), g[p + "obs0"], atol=1e-11)
+        full = {int(s): k for k, s in enumerate(g[p + "full_steps"])}
+        acts = g[p + "actions"]
+        for i in range(len(acts)):
+            obs, frame, rew, sr, done, info = env.step(i, acts[i])
+            np.testing.assert_allclose(obs, g[p + "obs"][i], atol=1e-10)
+            np.testing.assert_allclose(rew, g[p + "reward"][i], atol=1e-10)
+            np.testing.assert_allclose(sr, g[p + "strehl"][i], atol=1e-12)
+            np.testing.assert_allclose(env.total[i], g[p + "total"][i], atol=1e-9)
+            np.testing.assert_allclose(env.residual[i], g[p + "residual"][i], atol=1e-9)
+            np.testing.assert_allclose(env.wfs.signal, g[p + "signal"][i], atol=1e-11)
+            np.testing.assert_allclose(env.coefs, g[p + "coefs"][i], atol=1e-18)
+            for l, lay in enumerate(env.atm.layers):
+                np.testing.assert_allclose(lay.buff, g[p + "buff"][i, l], atol=1e-13)
+            if i in full:
+                k = full[i]
+                np.testing.assert_allclose(env.atm.OPD, g[p + "opd_atm"][k], atol=1e-18)
+                np.testing.assert_allclose(env.tel_OPD, g[p + "opd_res"][k], atol=1e-18)
+                np.testing.assert_allclose(frame, g[p + "frame"][k], atol=1e-8 * g[p + "frame"][k].max())
+                assert done is False
