@@ -1,0 +1,184 @@
+/*
+ * aoenv.h -- C ABI of the MI355X-native batched adaptive-optics environment (libaoenv.so).
+ *
+ * The reference (artiom-matvei/RLAO) is pure Python: there is no native FFI to mirror.  Each entry
+ * point below names the reference *Python* interface it replaces, so that a maintainer can bind the
+ * library behind drl4ao's gym-style env (INTEGRATION.md shows the ctypes stub):
+ *
+ *   OOPAO/  = drl4ao/AO_OOPAO/OOPAO/          MAIN/ = drl4ao/MAIN_CODE/
+ *
+ * Conventions
+ *   - plain C types only; every function returns 0 on success, non-zero on error and never throws or
+ *     aborts; aoenv_last_error() returns a thread-local description of the last failure.
+ *   - "d_" pointers are DEVICE pointers owned by the caller (PyTorch tensors, hipMalloc, ...), laid
+ *     out contiguously, element type = the environment's dtype (AOENV_F32 float / AOENV_F64 double).
+ *   - "h_" pointers are HOST pointers; constants are always handed over as float64 / int32 / uint8 and
+ *     converted to the environment's dtype on upload.
+ *   - stream arguments are hipStream_t passed as void* (NULL = the default stream).  All work of a
+ *     call is enqueued on that stream; no call synchronises the device except aoenv_download().
+ *   - one host thread per AoEnv; one AoEnv per GPU shard of independent AO loops ("envs").
+ */
+#ifndef AOENV_H
+#define AOENV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AOENV_ABI_VERSION 1
+
+enum { AOENV_F32 = 0, AOENV_F64 = 1 };
+enum { AOENV_WFS_SH = 0, AOENV_WFS_PYRAMID = 1 };
+
+/* Geometry and loop constants of one shard.  Filled by the host (rlao_amd/calib.py) from the same
+ * parameter-file keys the reference uses (MAIN/Conf/parameterFile_oopao_parser.py:19-79). */
+typedef struct AoEnv AoEnv;   /* opaque */
+
+typedef struct AoCfg {
+    int32_t abi_version;     /* = AOENV_ABI_VERSION */
+    int32_t dtype;           /* AOENV_F32 | AOENV_F64: arithmetic type of device state and kernels */
+    int32_t n_env;           /* independent AO loops stepped in lock-step on this GPU */
+    int32_t resolution;      /* R: telescope pupil pixels across the diameter (OOPAO/Telescope.py:138) */
+    int32_t n_layer;         /* turbulence layers; 0 = no atmosphere (calibration shards) */
+    int32_t layer_res;       /* N: interior size of a layer screen, N = R + 4 for fov 0 (OOPAO/Atmosphere.py:216-218) */
+    int32_t n_inner;         /* 8N-16 : conditioning ring pixels Z (OOPAO/Atmosphere.py:267-274) */
+    int32_t n_outer;         /* 4N+4  : regenerated ring pixels X */
+    int32_t n_act;           /* actuators across the diameter, nSubap+1 (OOPAO/DeformableMirror.py:288) */
+    int32_t n_valid_act;     /* A: controlled actuators */
+    int32_t dm_separable;    /* 1: OPD = Gy C Gx^T (Cartesian Gaussian DM, no rotation); 0: dense modes GEMM */
+    int32_t wfs_type;        /* AOENV_WFS_SH | AOENV_WFS_PYRAMID */
+    int32_t n_subap;         /* lenslets (SH) / pupil samples (Pyramid) across the diameter */
+    int32_t n_valid_subap;   /* SH: valid lenslets;  Pyramid: valid pixels per quadrant */
+    int32_t n_signal;        /* length of wfs.signal */
+    int32_t cam_res;         /* WFS camera frame is cam_res x cam_res */
+    int32_t n_loop;          /* length of the total[] / residual[] telemetry (param['nLoop']) */
+    int32_t max_group;       /* envs in consecutive groups of max_group share the centroid-threshold
+                                maximum (1 in the loop; nMeasurements when emulating the batched
+                                interaction-matrix measurement, OOPAO/ShackHartmann.py:605-672) */
+    int32_t pyr_n_res;       /* Pyramid: padded FFT size nRes (OOPAO/Pyramid.py:251) */
+    int32_t pyr_n_theta;     /* Pyramid: modulation points (1 = unmodulated) */
+    double  atm_wavelength;  /* 500e-9: wavelength the screens are expressed at (OOPAO/Atmosphere.py:134) */
+    double  src_wavelength;  /* guide-star wavelength (OOPAO/Source.py:102) */
+    double  leak;            /* leaky-integrator factor (MAIN/OOPAOEnv/OOPAOEnv.py:69) */
+    double  threshold_cog;   /* SH centre-of-gravity threshold (OOPAO/ShackHartmann.py:42) */
+} AoCfg;
+
+/* Constant tables, uploaded once per geometry (aoenv_upload).  Element type on the host side in []. */
+enum AoConst {
+    AOENV_C_PUPIL = 0,       /* [u8  R*R]            Telescope.pupil                                  */
+    AOENV_C_AB,              /* [f64 n_outer*(n_inner+n_outer)] rows = [A | B] (OOPAO/Atmosphere.py:284-286) */
+    AOENV_C_INNER_IDX,       /* [i32 n_inner]  flat index into the (N+2)^2 screen of each Z pixel, mask order */
+    AOENV_C_OUTER_IDX,       /* [i32 n_outer]  flat index of each X pixel, mask order                  */
+    AOENV_C_LAYER_WEIGHT,    /* [f64 n_layer]  sqrt(fractionalR0) (OOPAO/Atmosphere.py:450)            */
+    AOENV_C_DM_GX,           /* [f64 R*n_act]  separable influence factor along x                      */
+    AOENV_C_DM_GY,           /* [f64 R*n_act]  separable influence factor along y                      */
+    AOENV_C_DM_MODES,        /* [f64 R*R*A]    dense influence matrix dm.modes (only if !dm_separable)  */
+    AOENV_C_ACT_IDX,         /* [i32 A]        iy*n_act+ix of each valid actuator (xvalid,yvalid)       */
+    AOENV_C_WFS_AMP,         /* [f64 R*R]      sqrt(src.fluxMap) (x pupilReflectivity)                  */
+    AOENV_C_SH_SUBAP_IDX,    /* [i32 n_valid_subap] i*n_subap+j of each valid lenslet                   */
+    AOENV_C_SH_REF,          /* [f64 2*n_valid_subap] reference centroids (x block then y block)        */
+    AOENV_C_WFS_UNITS,       /* [f64 1]        slopes_units                                             */
+    AOENV_C_RECON,           /* [f64 A*n_signal] reconstructor = M2C @ calib.M (MAIN/OOPAOEnv/OOPAOEnv.py:381) */
+    AOENV_C_COUNT
+};
+
+/* Device buffers that can be inspected / overwritten (aoenv_download / aoenv_upload_state): the
+ * environment state of SURVEY.md section 5 "checkpoint / resume" plus the stage boundaries the parity
+ * tests compare.  Shapes are per shard, leading dimension n_env unless noted. */
+enum AoBuf {
+    AOENV_B_SCREEN = 0,      /* [n_layer][n_env][(N+2)^2]  layer.mapShift                                */
+    AOENV_B_OPD_ATM,         /* [n_env][R*R]   atm.OPD_no_pupil                                          */
+    AOENV_B_COEFS,           /* [n_env][A]     dm.coefs                                                  */
+    AOENV_B_PHASE,           /* [n_env][R*R]   tel.src.phase (residual, pupil-masked, rad @ src)          */
+    AOENV_B_FRAME,           /* [n_env][cam^2] wfs.cam.frame                                             */
+    AOENV_B_SIGNAL,          /* [n_env][n_signal] wfs.signal                                             */
+    AOENV_B_TOTAL,           /* [n_loop][n_env] env.total  (nm rms)                                      */
+    AOENV_B_RESIDUAL,        /* [n_loop][n_env] env.residual (nm rms)                                    */
+    AOENV_B_WFS_MAX,         /* [n_env]        max of the valid spot intensities (threshold reference)   */
+    AOENV_B_XI,              /* [n_env][n_inner+n_outer] last [Z | xi] operand of the ring extrusion      */
+    AOENV_B_COUNT
+};
+
+const char* aoenv_last_error(void);
+int aoenv_abi_version(void);
+
+/* Replaces: OOPAO() + the object construction half of set_params() (MAIN/OOPAOEnv/OOPAOEnv.py:19-73,
+ * 121-246): allocates all device state for cfg->n_env loops on HIP device `device`.  The DM starts
+ * flat (dm.coefs = 0), the atmosphere OPD at zero, the WFS reference at zero and units at 1. */
+int aoenv_create(const AoCfg* cfg, int device, AoEnv** out);
+int aoenv_destroy(AoEnv* env);
+
+/* Replaces: the constant members the reference objects compute in their constructors (pupil, layer.A /
+ * layer.B, dm.modes, wfs flux / reference / units, env.reconstructor ...).  `kind` is an AoConst;
+ * `bytes` must match the table size implied by the AoCfg.  May be called again at any time (e.g. the
+ * r0 setter re-uploads [A|B], OOPAO/Atmosphere.py:792-807). */
+int aoenv_upload(AoEnv* env, int kind, const void* h_data, size_t bytes);
+
+/* Replaces: the windSpeed / windDirection setters (OOPAO/Atmosphere.py:829-873): per layer
+ * ratio = (vX, vY) * samplingTime / pixel_size in pixels per frame (OOPAO/Atmosphere.py:362-363).
+ * h_ratio is [n_layer][2] float64, shared by all envs of the shard.  `reset_buff` != 0 also clears the
+ * sub-pixel accumulator (what notDoneOnce does after generateNewPhaseScreen). */
+int aoenv_set_wind(AoEnv* env, const double* h_ratio, int reset_buff);
+
+/* Replaces: atm.generateNewPhaseScreen(seed) (OOPAO/Atmosphere.py:560-592) for every env of the shard.
+ *   h_screens [n_env][n_layer][N*N] float64: the new layer.phase screens (rad @ 500 nm), or NULL to keep
+ *             the current interior;
+ *   h_ring_seeds [n_env][n_layer] uint32: seeds of the per-layer ring RandomState (seed + 1000*layer);
+ * seeds every MT19937 stream, draws the first ring X = A.Z + B.xi on the device, rebuilds mapShift,
+ * clears the sub-pixel accumulators and refreshes atm.OPD (fill_phase_support + set_OPD). */
+int aoenv_new_screens(AoEnv* env, const double* h_screens, const uint32_t* h_ring_seeds, void* stream);
+
+/* Replaces: atm.update(OPD) with a user-defined OPD (OOPAO/Atmosphere.py:421-425) and
+ * tel.OPD = ... in the WFS calibration (OOPAO/ShackHartmann.py:296-297).  h_opd [n_env][R*R] float64
+ * (no pupil applied); only meaningful while n_layer == 0 or until the next aoenv_step. */
+int aoenv_set_atm_opd(AoEnv* env, const double* h_opd, void* stream);
+
+/* Replaces: dm.coefs = v (OOPAO/DeformableMirror.py:534-570).  h_coefs [n_env][A] float64 or NULL for
+ * dm.coefs = 0 (MAIN/PO4AO/mbrl.py:50). */
+int aoenv_set_coefs(AoEnv* env, const double* h_coefs, void* stream);
+
+/* Replaces: tel*dm*wfs with no atmosphere update (MAIN/PO4AO/mbrl.py:52; OOPAO/Telescope.py:533-544,
+ * 476-485): residual phase = (atm.OPD_no_pupil + dm.OPD) * pupil, WFS measurement, signal. */
+int aoenv_measure(AoEnv* env, void* stream);
+
+/* Replaces: env.reset_soft() (MAIN/OOPAOEnv/OOPAOEnv.py:82-86): obs = vec_to_img(-R @ wfs.signal) * 1e6.
+ * d_obs [n_env][n_act][n_act]. */
+int aoenv_reset_soft(AoEnv* env, void* d_obs, void* stream);
+
+/* Replaces: env.step(i, action) (MAIN/OOPAOEnv/OOPAOEnv.py:485-536; Razor twin OOPAOEnvRazor.py:474-514).
+ *   i        frame index: total[i], residual[i] are written (i < n_loop)
+ *   d_action [n_env][n_act][n_act]  DM increment image in micrometres
+ *   d_obs    [n_env][n_act][n_act]  out: reconstructed residual image (micrometres)
+ *   d_frame  [n_env][cam][cam] or NULL  out: wfs.cam.frame (Papyrus 6-tuple) / NULL (Razor 5-tuple)
+ *   d_reward [n_env]  out: -||obs||_2        d_strehl [n_env]  out: exp(-var(phase[pupil]))
+ * Order of effects as in the reference: turbulence advances, the WFS sees the command latched by the
+ * previous call, then dm.coefs <- leak * dm.coefs + 1e-6 * img_to_vec(action). */
+int aoenv_step(AoEnv* env, int i, const void* d_action, void* d_obs, void* d_frame, void* d_reward,
+               void* d_strehl, void* stream);
+
+/* Closed-loop driver of MAIN/integrator_oopao_razor.py:66-91 kept on the device: n_steps iterations of
+ * action = gain * obs; obs, reward, strehl = step(i0 + k, action).  d_obs is in/out. */
+int aoenv_run_integrator(AoEnv* env, int i0, int n_steps, double gain, void* d_obs, void* d_frame,
+                         void* d_reward, void* d_strehl, void* stream);
+
+/* State access (get_state / set_state; also the stage boundaries compared by the
+ * parity tests).  `which` is an AoBuf.  aoenv_buffer returns the device pointer and size in bytes;
+ * aoenv_download copies to a host buffer of the env dtype and synchronises the stream. */
+int aoenv_buffer(AoEnv* env, int which, void** d_ptr, size_t* bytes);
+int aoenv_download(AoEnv* env, int which, void* h_dst, size_t bytes, void* stream);
+int aoenv_upload_state(AoEnv* env, int which, const void* h_src, size_t bytes, void* stream);
+/* host-side atmosphere clock: h_buff [n_layer][2] float64 (layer.buff, OOPAO/Atmosphere.py:392-404) */
+int aoenv_get_buff(AoEnv* env, double* h_buff);
+int aoenv_set_buff(AoEnv* env, const double* h_buff);
+
+/* Test hook: draw `n` (even) values of RandomState(seed).normal(size=n) with the device MT19937 +
+ * legacy polar generator into h_out (float64), to pin the stream against NumPy. */
+int aoenv_test_normal(int device, uint32_t seed, int n, int n_calls, double* h_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,355 @@
+"""Host-side (NumPy float64) constants of the batched AO environment.
+
+Everything here runs once per geometry at ``set_params`` time and produces the tables that
+``libaoenv`` consumes (include/aoenv.h, ``enum AoConst``).  The per-step physics never runs here: the
+wave-front-sensor calibration itself (reference slopes, slope units, interaction matrix) is measured
+on the GPU by the same HIP kernels the loop uses, in float64 (rlao_amd/env.py).
+
+Reference parity citations:  OOPAO/ = drl4ao/AO_OOPAO/OOPAO/ ,  MAIN/ = drl4ao/MAIN_CODE/ .
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from types import SimpleNamespace
+from typing import Sequence
+
+import numpy as np
+
+ATM_WAVELENGTH = 500e-9           # OOPAO/Atmosphere.py:134
+R0_DEF = 0.15                     # OOPAO/Atmosphere.py:124
+
+# (wavelength, bandwidth, zero point) -- OOPAO/Source.py:170-232
+PHOTOMETRY = {
+    "U": (0.360e-6, 0.070e-6, 1.96e12), "B": (0.440e-6, 0.100e-6, 5.38e12), "V0": (0.500e-6, 0.090e-6, 3.64e12),
+    "V": (0.550e-6, 0.090e-6, 3.31e12), "R": (0.640e-6, 0.150e-6, 4.01e12), "R2": (0.650e-6, 0.300e-6, 7.9e12),
+    "R3": (0.600e-6, 0.300e-6, 8.56e12), "R4": (0.670e-6, 0.300e-6, 7.66e12), "I": (0.790e-6, 0.150e-6, 2.69e12),
+    "I1": (0.700e-6, 0.033e-6, 0.67e12), "I2": (0.750e-6, 0.033e-6, 0.62e12), "I3": (0.800e-6, 0.033e-6, 0.58e12),
+    "I4": (0.700e-6, 0.100e-6, 2.02e12), "I5": (0.850e-6, 0.100e-6, 1.67e12), "I6": (1.000e-6, 0.100e-6, 1.42e12),
+    "I7": (0.850e-6, 0.300e-6, 5.00e12), "I8": (0.750e-6, 0.100e-6, 1.89e12), "I9": (0.850e-6, 0.300e-6, 5.00e12),
+    "I10": (0.900e-6, 0.300e-6, 4.72e12), "J": (1.215e-6, 0.260e-6, 1.90e12), "J2": (1.550e-6, 0.260e-6, 1.49e12),
+    "H": (1.654e-6, 0.290e-6, 1.05e12), "Kp": (2.1245e-6, 0.351e-6, 0.62e12), "Ks": (2.157e-6, 0.320e-6, 0.55e12),
+    "K": (2.179e-6, 0.410e-6, 0.70e12), "K0": (2.000e-6, 0.410e-6, 0.76e12), "K1": (2.400e-6, 0.410e-6, 0.64e12),
+    "L": (3.547e-6, 0.570e-6, 2.5e11), "M": (4.769e-6, 0.450e-6, 8.4e10), "Na": (0.589e-6, 0, 3.3e12),
+    "EOS": (1.064e-6, 0, 3.3e12), "IR1310": (1.310e-6, 0, 2e12),
+}
+
+
+# ------------------------------------------------------------------------------------------------------
+# Parameters: the keys of MAIN/Conf/parameterFile_oopao_parser.py:19-79 (+ the Razor spelling fractionalR0)
+# ------------------------------------------------------------------------------------------------------
+@dataclass
+class AOParams:
+    diameter: float = 8.0
+    nSubaperture: int = 20
+    nPixelPerSubap: int = 6
+    samplingTime: float = 1 / 500
+    centralObstruction: float = 0.0
+    magnitude: float = 8.0
+    opticalBand: str = "I"
+    mechanicalCoupling: float = 0.35
+    r0: float = 0.13
+    L0: float = 30.0
+    fractionalR0: Sequence[float] = (1.0,)
+    windSpeed: Sequence[float] = (10.0,)
+    windDirection: Sequence[float] = (72.0,)
+    altitude: Sequence[float] = (0.0,)
+    nLoop: int = 10000
+    gainCL: float = 0.5
+    leak: float = 0.99
+    lightThreshold: float = 0.5          # SH lightRatio (MAIN/OOPAOEnv/OOPAOEnvRazor.py:236)
+    threshold_cog: float = 0.01          # OOPAO/ShackHartmann.py:42
+    nModes: int = 50                     # Zernike modes kept from the M2C (MAIN/OOPAOEnv/OOPAOEnv.py:260)
+    nMeasurements: int = 6               # MAIN/OOPAOEnv/OOPAOEnv.py:285
+    fov: float = 0.0
+    extra: dict = field(default_factory=dict)
+
+    @property
+    def resolution(self) -> int:
+        return int(self.nSubaperture * self.nPixelPerSubap)
+
+    @property
+    def nActuator(self) -> int:
+        return int(self.nSubaperture + 1)
+
+    @property
+    def nLayer(self) -> int:
+        return len(self.fractionalR0)
+
+
+def params_from_args(args=None, **overrides) -> AOParams:
+    """Accepts the YAML namespace / dict the reference passes to ``set_params`` (MAIN/PO4AO/mbrl.py:22-31)."""
+    src = {}
+    if args is not None:
+        src = dict(vars(args)) if isinstance(args, SimpleNamespace) or hasattr(args, "__dict__") else dict(args)
+    src.update(overrides)
+    if "fractionnalR0" in src and "fractionalR0" not in src:       # [sic] Papyrus spelling
+        src["fractionalR0"] = src.pop("fractionnalR0")
+    p = AOParams()
+    known = set(AOParams.__dataclass_fields__) - {"extra"}
+    for k, v in src.items():
+        if k in known:
+            setattr(p, k, v)
+        else:
+            p.extra[k] = v
+    for k in ("fractionalR0", "windSpeed", "windDirection", "altitude"):
+        setattr(p, k, [float(x) for x in getattr(p, k)])
+    n = p.nLayer
+    if not (len(p.windSpeed) == len(p.windDirection) == len(p.altitude) == n):
+        raise ValueError("fractionalR0, windSpeed, windDirection and altitude must have one entry per layer")
+    if any(a != 0 for a in p.altitude) and p.fov != 0:
+        raise NotImplementedError("layers above the ground with a non-zero field of view are out of scope (SURVEY 8a A9)")
+    return p
+
+
+# ------------------------------------------------------------------------------------------------------
+# Telescope / source
+# ------------------------------------------------------------------------------------------------------
+def telescope_pupil(resolution: int, central_obstruction: float = 0.0) -> np.ndarray:
+    """Circular pupil mask (OOPAO/Telescope.py:164-180)."""
+    x = np.linspace(-resolution / 2, resolution / 2, resolution)
+    r2 = x[None, :] ** 2 + x[:, None] ** 2
+    rim = (resolution + 1) / 2
+    return (r2 < rim ** 2) & (r2 >= (central_obstruction * rim) ** 2)
+
+
+def source(band: str, magnitude: float):
+    """(wavelength, nPhoton) of a natural guide star (OOPAO/Source.py:100-109)."""
+    if band not in PHOTOMETRY:
+        raise ValueError(f"unknown optical band {band!r}")
+    wl, _, zp = PHOTOMETRY[band]
+    return wl, (zp / 368) * 10 ** (-0.4 * magnitude)
+
+
+# ------------------------------------------------------------------------------------------------------
+# Atmosphere tables
+# ------------------------------------------------------------------------------------------------------
+def _vk_covariance(za: np.ndarray, zb: np.ndarray, L0: float) -> np.ndarray:
+    """von Karman phase covariance at r0_def (OOPAO/phaseStats.py:70-133)."""
+    from scipy.special import kv
+    rho = np.abs(za[:, None] - zb[None, :])
+    ratio = (L0 / R0_DEF) ** (5.0 / 3)
+    g = math.gamma
+    head = (24.0 * g(6.0 / 5) / 5) ** (5.0 / 6)
+    cst = head * (g(11.0 / 6) / ((2.0 ** (5.0 / 6)) * np.pi ** (8.0 / 3))) * ratio
+    out = np.ones(rho.shape) * head * (g(11.0 / 6) * g(5.0 / 6) / (2 * np.pi ** (8.0 / 3))) * ratio
+    nz = rho != 0
+    u = 2 * np.pi * rho[nz] / L0
+    out[nz] = cst * u ** (5.0 / 6) * kv(5.0 / 6, u)
+    return out
+
+
+class AtmosphereTables:
+    """Geometry shared by every layer when fov = 0 (OOPAO/Atmosphere.py:192-298)."""
+
+    def __init__(self, p: AOParams):
+        R, D = p.resolution, p.diameter
+        if p.fov != 0:
+            raise NotImplementedError("fov != 0")
+        self.N = N = R + 4
+        self.S = S = N + 2
+        self.layer_D = N * D / R
+        self.ps_loop = self.layer_D / N                        # :351
+        ring = np.zeros((S, S), bool)
+        ring[0, :] = ring[-1, :] = ring[:, 0] = ring[:, -1] = True
+        inner = ~ring
+        inner[3:-3, 3:-3] = False
+        self.outer_mask, self.inner_mask = ring, inner
+        self.outer_idx = np.flatnonzero(ring).astype(np.int32)   # boolean-mask (row-major) order, :291, :309
+        self.inner_idx = np.flatnonzero(inner).astype(np.int32)
+        self.n_outer, self.n_inner = self.outer_idx.size, self.inner_idx.size
+        axis = np.linspace(0, N + 1, N + 2) * self.layer_D / (N - 1)          # :271
+        u, v = np.meshgrid(axis, axis)
+        zin = (u + 1j * v)[inner]
+        zout = (u + 1j * v)[ring]
+        self._zz = _vk_covariance(zin, zin, p.L0)
+        self._zx = _vk_covariance(zin, zout, p.L0)
+        self._xx = _vk_covariance(zout, zout, p.L0)
+        self._zz_inv = np.linalg.pinv(self._zz)
+        self.weights = np.sqrt(np.asarray(p.fractionalR0, float))
+        self.set_r0(p.r0)
+
+    def set_r0(self, r0: float):
+        """A = ZXt^T ZZt^-1, B = chol(XXt - A ZXt) at the requested r0 (:284-286, :554-557)."""
+        s = (R0_DEF / r0) ** (5.0 / 3)
+        self.A = np.matmul((self._zx * s).T, self._zz_inv / s)
+        self.B = np.linalg.cholesky(self._xx * s - np.matmul(self.A, self._zx * s))
+        self.AB = np.ascontiguousarray(np.concatenate([self.A, self.B], axis=1))
+
+    def wind_ratio(self, speeds, directions, dt):
+        """pixels per frame along (x, y) for each layer (:209-210, :352-363)."""
+        out = np.zeros((len(speeds), 2))
+        for l, (ws, wd) in enumerate(zip(speeds, directions)):
+            vy = ws * np.cos(np.deg2rad(wd))
+            vx = ws * np.sin(np.deg2rad(wd))
+            out[l] = [vx * dt / self.ps_loop, vy * dt / self.ps_loop]
+        return out
+
+
+def new_phase_screen(r0: float, L0: float, n: int, delta: float, seed: int) -> np.ndarray:
+    """One N x N von Karman screen in rad @ 500 nm: FFT screen + 3 sub-harmonic grids
+    (OOPAO/phaseStats.py:190-318).  Kept quirks: both generators start from the same seed (:268, :272) and
+    only the i, j in {0, 1} corner of each 3 x 3 sub-harmonic grid is summed (:306-309)."""
+    l0 = 1e-10
+    fm = 5.92 / l0 / (2 * np.pi)
+    f0 = 1.0 / L0
+
+    def psd_of(f):
+        return 0.023 * r0 ** (-5.0 / 3) * np.exp(-1 * (f / fm) ** 2) / ((f ** 2 + f0 ** 2) ** (11.0 / 6))
+
+    rs = np.random.RandomState(seed)
+    del_f = 1.0 / (n * delta)
+    fx = np.arange(-n / 2.0, n / 2.0) * del_f
+    fx, fy = np.meshgrid(fx, fx)
+    psd = psd_of(np.sqrt(fx ** 2 + fy ** 2))
+    psd[int(n / 2), int(n / 2)] = 0
+    cn = (rs.normal(size=(n, n)) + 1j * rs.normal(size=(n, n))) * np.sqrt(psd) * del_f
+    hi = np.fft.fftshift(np.fft.fft2(np.fft.fftshift(cn))).real
+
+    rs = np.random.RandomState(seed)
+    D = n * delta
+    coords = np.arange(-n / 2, n / 2) * delta
+    x, y = np.meshgrid(coords, coords)
+    lo = np.zeros((n, n), complex)
+    for p in range(1, 4):
+        del_f = 1 / (3 ** p * D)
+        fx = np.arange(-1, 2) * del_f
+        fx, fy = np.meshgrid(fx, fx)
+        psd = psd_of(np.sqrt(fx ** 2 + fy ** 2))
+        psd[1, 1] = 0
+        cn = (rs.normal(size=(3, 3)) + 1j * rs.normal(size=(3, 3))) * np.sqrt(psd) * del_f
+        sh = np.zeros((n, n), complex)
+        for i in range(2):
+            for j in range(2):
+                sh += cn[i, j] * np.exp(1j * 2 * np.pi * (fx[i, j] * x + fy[i, j] * y))
+        lo = lo + sh
+    lo = lo.real - lo.real.mean()
+    return lo + hi
+
+
+# ------------------------------------------------------------------------------------------------------
+# Deformable mirror
+# ------------------------------------------------------------------------------------------------------
+class DMTables:
+    """Cartesian Fried-geometry DM with Gaussian influence functions and zero mis-registration
+    (OOPAO/DeformableMirror.py:286-305 valid actuators, :494-514 influence model).  With no rotation /
+    anamorphosis the influence function of actuator (iy, ix) is gy[:, iy] (x) gx[:, ix]."""
+
+    def __init__(self, p: AOParams, pitch: float | None = None):
+        R, D, ns = p.resolution, p.diameter, p.nSubaperture
+        self.nAct = nAct = ns + 1
+        self.pitch = D / nAct if pitch is None else pitch        # MAIN/OOPAOEnv/OOPAOEnv.py:228
+        x = np.linspace(-D / 2, D / 2, nAct)
+        X, Y = np.meshgrid(x, x)
+        rad = np.sqrt(X.reshape(-1) ** 2 + Y.reshape(-1) ** 2)
+        self.validAct = (rad > (p.centralObstruction * D / 2 - 0.5 * self.pitch)) & (rad <= (D / 2 + 0.7533 * self.pitch))
+        self.act_idx = np.flatnonzero(self.validAct).astype(np.int32)       # iy * nAct + ix
+        self.nValidAct = int(self.act_idx.size)
+        self.dm_mask = self.validAct.reshape(nAct, nAct)
+        self.xvalid, self.yvalid = np.nonzero(self.dm_mask)                 # MAIN/OOPAOEnv/OOPAOEnv.py:231-232
+        centre = R / 2 + x * R / D
+        width = (R / ns) / np.sqrt(2 * np.log(1.0 / p.mechanicalCoupling))
+        pix = np.linspace(0, 1, R) * R
+        self.gx = np.exp(-((pix[:, None] - centre[None, :]) ** 2) / (2 * width ** 2))     # [R, nAct]
+        self.gy = self.gx.copy()
+        self._R = R
+        self._centre, self._a, self._pix = centre, 1.0 / (2 * width ** 2), pix
+
+    def dense_modes(self) -> np.ndarray:
+        """dm.modes [R*R, nValidAct], evaluated with the reference's own expression (:506-511)."""
+        XX, YY = np.meshgrid(self._pix, self._pix)
+        x0 = self._centre[self.act_idx % self.nAct]
+        y0 = self._centre[self.act_idx // self.nAct]
+        a = self._a
+        return np.exp(-(a * (XX.reshape(-1, 1) - x0[None, :]) ** 2 + a * (YY.reshape(-1, 1) - y0[None, :]) ** 2))
+
+
+# ------------------------------------------------------------------------------------------------------
+# Shack-Hartmann geometry
+# ------------------------------------------------------------------------------------------------------
+class SHTables:
+    """Valid-lenslet selection and field amplitude (OOPAO/ShackHartmann.py:154-236, 327-338)."""
+
+    def __init__(self, p: AOParams, pupil: np.ndarray, n_photon: float):
+        R, ns = p.resolution, p.nSubaperture
+        self.p = px = R // ns
+        self.n = 2 * px
+        self.cam_res = ns * px
+        self.flux_map = pupil.astype(float) * n_photon * p.samplingTime * (p.diameter / R) ** 2   # OOPAO/Source.py:151
+        # lenslet k = i*ns + j sees flux_map.T[j*px:(j+1)*px, i*px:(i+1)*px]  (:331-335)
+        per = self.flux_map.T.reshape(ns, px, ns, px).sum(axis=(1, 3)).T.reshape(-1)
+        self.valid_1d = per >= p.lightThreshold * per.max()
+        self.valid_2d = self.valid_1d.reshape(ns, ns)
+        self.subap_idx = np.flatnonzero(self.valid_1d).astype(np.int32)
+        self.nValid = int(self.subap_idx.size)
+        self.nSignal = 2 * self.nValid
+        self.amp = np.sqrt(self.flux_map)
+
+
+def tip_ramp(R: int) -> np.ndarray:
+    """Unit tip used for the slope-unit calibration (OOPAO/ShackHartmann.py:286-290).  The reference
+    normalises with ``np.std(Tip[tel.pupil])`` where tel.pupil is an *integer* 0/1 array, i.e. the std of
+    whole rows 0 / 1 of the ramp = the std of one row; kept as is."""
+    tip, _ = np.meshgrid(np.linspace(0, np.pi, R, endpoint=False), np.linspace(0, np.pi, R, endpoint=False))
+    return tip * (1 / np.std(tip[0]))
+
+
+# ------------------------------------------------------------------------------------------------------
+# Modal basis and reconstructor
+# ------------------------------------------------------------------------------------------------------
+def _noll(j: int):
+    n = int((-1.0 + np.sqrt(8 * (j - 1) + 1)) / 2.0)
+    k = n % 2
+    m = int(((j - (n * (n + 1)) / 2.0) + k) / 2.0) * 2 - k
+    if m != 0:
+        m *= 1 if j % 2 == 0 else -1
+    return n, m
+
+
+def _radial(n: int, m: int, r: np.ndarray) -> np.ndarray:
+    out = np.zeros(r.shape)
+    for i in range(0, int((n - m) / 2) + 1):
+        out += r ** (n - 2.0 * i) * (((-1) ** i) * math.factorial(n - i)) / (
+            math.factorial(i) * math.factorial(int(0.5 * (n + m) - i)) * math.factorial(int(0.5 * (n - m) - i)))
+    return out
+
+
+def zernike_basis(pupil: np.ndarray, D: float, n_modes: int) -> np.ndarray:
+    """Noll Zernike modes 2..n_modes+1 on the pupil pixels, mean-removed, unit std (OOPAO/Zernike.py:26-66)."""
+    R = pupil.shape[0]
+    X, Y = np.where(pupil > 0)
+    X = (X - (R + R % 2 - 1) / 2) / R * D
+    Y = (Y - (R + R % 2 - 1) / 2) / R * D
+    rr = np.sqrt(X ** 2 + Y ** 2)
+    rr = rr / rr.max()
+    th = np.arctan2(Y, X)
+    out = np.zeros((X.size, n_modes))
+    for i in range(1, n_modes + 1):
+        n, m = _noll(i + 1)
+        if m == 0:
+            Z = np.sqrt(n + 1) * _radial(n, 0, rr)
+        elif m > 0:
+            Z = np.sqrt(2 * (n + 1)) * _radial(n, m, rr) * np.cos(m * th)
+        else:
+            Z = np.sqrt(2 * (n + 1)) * _radial(n, -m, rr) * np.sin(-m * th)
+        Z = Z - Z.mean()
+        out[:, i - 1] = Z * (1 / np.std(Z))
+    return out
+
+
+def zernike_m2c(dm: DMTables, pupil: np.ndarray, D: float, n_modes: int) -> np.ndarray:
+    """M2C = pinv(dm.modes[pupil]) @ Z.modes  (MAIN/OOPAOEnv/OOPAOEnv.py:258, OOPAOEnvRazor.py:261)."""
+    modes = dm.dense_modes()[pupil.reshape(-1)]
+    return np.linalg.pinv(modes) @ zernike_basis(pupil, D, n_modes)
+
+
+def svd_inverse(D: np.ndarray) -> np.ndarray:
+    """calib.M = V^T S^-1 U^T  (OOPAO/calibration/CalibrationVault.py:19-30)."""
+    U, s, Vt = np.linalg.svd(D, full_matrices=False)
+    return Vt.T @ np.diag(1 / s) @ U.T
+
+
+def reconstructor_from_imat(imat: np.ndarray, m2c: np.ndarray):
+    """(reconstructor, F) of MAIN/OOPAOEnv/OOPAOEnv.py:295, 381-383."""
+    M = svd_inverse(imat @ m2c)
+    return m2c @ M, m2c @ np.linalg.pinv(m2c)

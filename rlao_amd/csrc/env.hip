@@ -1,0 +1,682 @@
+// Host side of libaoenv: the AoEnv object, the atmosphere clock and the C ABI of include/aoenv.h.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "common.hpp"
+
+namespace ao {
+
+static thread_local std::string g_err;
+
+int fail(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return 1;
+}
+
+struct LayerClock {
+    double ratio[2] = {0, 0};   // pixels per frame (x, y)          OOPAO/Atmosphere.py:362-363
+    double buff[2] = {0, 0};    // sub-pixel accumulator            OOPAO/Atmosphere.py:392-404
+};
+
+}  // namespace ao
+
+using namespace ao;
+
+struct AoEnv {
+    AoCfg c{};
+    int device = 0;
+    size_t esz = 4;
+    int R = 0, N = 0, S = 0, A = 0, nAct = 0, E = 0, L = 0, nin = 0, nout = 0, K = 0, nSig = 0, nSub = 0, nVal = 0;
+    int p = 0, n = 0, n_pupil = 0;
+    LayerClock clk[kMaxLayer];
+    int cur[kMaxLayer] = {0};
+    bool have[AOENV_C_COUNT] = {false};
+    double units = 1.0;
+    // device memory (element type = dtype unless noted)
+    void* screen[2] = {nullptr, nullptr};   // [L][E][S*S] ping-pong
+    void* minmax = nullptr;                 // [L][E][2]
+    uint32_t* mt_state = nullptr;           // [L][E][624]
+    int* mt_pos = nullptr;                  // [L][E]
+    void* zx = nullptr;                     // [E][K]  [Z | xi]
+    void* xbuf = nullptr;                   // [E][nout]
+    void* ab = nullptr;                     // [nout][K]
+    int* inner_idx = nullptr;
+    int* outer_idx = nullptr;
+    double layer_weight[kMaxLayer] = {0};
+    void* gx = nullptr;
+    void* gy = nullptr;
+    void* modes = nullptr;                  // [R*R][A]
+    void* dm_opd = nullptr;                 // [E][R*R] dense path
+    int* act_idx = nullptr;
+    uint8_t* pupil = nullptr;
+    void* opd_atm = nullptr;
+    void* coefs = nullptr;
+    void* phase = nullptr;
+    void* scal = nullptr;                   // [E][4]
+    void* total = nullptr;
+    void* residual = nullptr;
+    void* wfs_max = nullptr;
+    void* amp = nullptr;
+    int* subap_idx = nullptr;
+    void* sh_ref = nullptr;
+    void* tw = nullptr;
+    void* phs = nullptr;
+    void* frame = nullptr;
+    void* signal = nullptr;
+    void* recon = nullptr;                  // [A][nSig]
+    void* vbuf = nullptr;                   // [E][A]
+    void* obs_scratch = nullptr;            // [E][nAct*nAct]
+    std::vector<void*> allocs;
+
+    template <typename T> T* as(void* p_) const { return static_cast<T*>(p_); }
+    void* screen_ptr(int which, int l) const {
+        return static_cast<char*>(screen[which]) + (size_t)l * E * S * S * esz;
+    }
+    void* minmax_ptr(int l) const { return static_cast<char*>(minmax) + (size_t)l * E * 2 * esz; }
+};
+
+namespace {
+
+int dmalloc(AoEnv* env, void** p, size_t bytes, bool zero = true) {
+    if (bytes == 0) bytes = 16;
+    AO_HIP(hipMalloc(p, bytes));
+    env->allocs.push_back(*p);
+    if (zero) AO_HIP(hipMemset(*p, 0, bytes));
+    return 0;
+}
+
+template <typename T>
+int upload_f64(void* dst, const double* src, size_t n) {
+    std::vector<T> tmp(n);
+    for (size_t i = 0; i < n; ++i) tmp[i] = (T)src[i];
+    AO_HIP(hipMemcpy(dst, tmp.data(), n * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int upload_real(AoEnv* env, void* dst, const double* src, size_t n) {
+    return env->c.dtype == AOENV_F32 ? upload_f64<float>(dst, src, n) : upload_f64<double>(dst, src, n);
+}
+
+double sgn(double v) { return (v > 0) - (v < 0); }
+
+// Catmull-Rom tap weights of skimage's cubic_interpolation() for fractional offset x in [0, 1)
+void catmull_rom(double x, double w[4]) {
+    w[0] = 0.5 * (-x * x * x + 2 * x * x - x);
+    w[1] = 0.5 * (3 * x * x * x - 5 * x * x + 2);
+    w[2] = 0.5 * (-3 * x * x * x + 4 * x * x + x);
+    w[3] = 0.5 * (x * x * x - x * x);
+}
+
+void mt_seed(uint32_t seed, uint32_t* key) {          // numpy legacy mt19937_seed / init_genrand
+    for (int pos = 0; pos < kMtN; ++pos) {
+        key[pos] = seed;
+        seed = 1812433253u * (seed ^ (seed >> 30)) + (uint32_t)pos + 1u;
+    }
+}
+
+template <typename T>
+ShConst<T> sh_const(const AoEnv* env) {
+    ShConst<T> sc;
+    sc.amp = env->as<T>(env->amp);
+    sc.subap_idx = env->subap_idx;
+    sc.ref = env->as<T>(env->sh_ref);
+    sc.tw = env->as<T>(env->tw);
+    sc.ph = env->as<T>(env->phs);
+    sc.units = (T)env->units;
+    sc.threshold = (T)env->c.threshold_cog;
+    return sc;
+}
+
+// ---- add_row on the device (OOPAO/Atmosphere.py:301-311) for every env of the shard ---------------
+template <typename T>
+int extrude(AoEnv* env, int l, int sx, int sy, bool copy, hipStream_t st) {
+    const int from = env->cur[l], to = copy ? 1 - from : from;
+    T* oldm = env->as<T>(env->screen_ptr(from, l));
+    T* newm = env->as<T>(env->screen_ptr(to, l));
+    T* zx = env->as<T>(env->zx);
+    AO_TRY(launch_shift_gather<T>(oldm, newm, zx, env->inner_idx, env->E, env->S, env->nin, env->K, sx, sy, copy ? 1 : 0,
+                                  st));
+    AO_TRY(launch_mt_normal<T>(env->mt_state + (size_t)l * env->E * kMtN, env->mt_pos + (size_t)l * env->E, zx, env->E,
+                               env->K, env->nin, env->nout, st));
+    AO_TRY(launch_gemm_nt<T>(zx, env->as<T>(env->ab), env->as<T>(env->xbuf), env->E, env->nout, env->K, env->K, env->K,
+                             env->nout, st));
+    AO_TRY(launch_scatter_minmax<T>(newm, env->as<T>(env->xbuf), env->outer_idx, env->as<T>(env->minmax_ptr(l)), env->E,
+                                    env->S, env->nout, st));
+    env->cur[l] = to;
+    return 0;
+}
+
+// ---- atm.update(): host clock of updateLayer (OOPAO/Atmosphere.py:350-407) -----------------------
+template <typename T>
+int advance_atmosphere(AoEnv* env, hipStream_t st) {
+    for (int l = 0; l < env->L; ++l) {
+        LayerClock& k = env->clk[l];
+        if (k.ratio[0] == 0 && k.ratio[1] == 0) continue;
+        const int ns[2] = {(int)std::fabs(k.ratio[0]), (int)std::fabs(k.ratio[1])};
+        const int mn = ns[0] < ns[1] ? ns[0] : ns[1], mx = ns[0] > ns[1] ? ns[0] : ns[1];
+        const int s0 = (int)sgn(k.ratio[0]), s1 = (int)sgn(k.ratio[1]);
+        for (int i = 0; i < mn; ++i) AO_TRY(extrude<T>(env, l, s0, s1, true, st));
+        for (int j = 0; j < mx - mn; ++j)
+            AO_TRY(extrude<T>(env, l, ns[0] == mn ? 0 : s0, ns[1] == mn ? 0 : s1, true, st));
+        for (int d = 0; d < 2; ++d) k.buff[d] += std::fmod(std::fabs(k.ratio[d]), 1.0) * sgn(k.ratio[d]);
+        if (std::fabs(k.buff[0]) >= 1 || std::fabs(k.buff[1]) >= 1) {
+            const int b0 = std::fabs(k.buff[0]) < 1 ? 0 : (int)sgn(k.buff[0]);
+            const int b1 = std::fabs(k.buff[1]) < 1 ? 0 : (int)sgn(k.buff[1]);
+            AO_TRY(extrude<T>(env, l, b0, b1, true, st));
+        }
+        for (int d = 0; d < 2; ++d) k.buff[d] = std::fmod(std::fabs(k.buff[d]), 1.0) * sgn(k.buff[d]);
+    }
+    return 0;
+}
+
+template <typename T>
+int run_phase(AoEnv* env, int update_atm, int telemetry_index, hipStream_t st) {
+    PhaseArgs pa{};
+    pa.n_layer = env->L;
+    pa.S = env->S;
+    pa.foot = (env->N / 2 - env->R / 2) + 1;
+    pa.update_atm = (update_atm && env->L > 0) ? 1 : 0;
+    pa.telemetry_index = telemetry_index;
+    for (int l = 0; l < env->L; ++l) {
+        pa.screen[l] = env->screen_ptr(env->cur[l], l);
+        pa.minmax[l] = env->minmax_ptr(l);
+        LayerTaps& t = pa.taps[l];
+        const double fy = -env->clk[l].buff[1], fx = -env->clk[l].buff[0];
+        const double ky = std::floor(fy), kx = std::floor(fx);
+        t.dy = (int)ky;
+        t.dx = (int)kx;
+        catmull_rom(fy - ky, t.wy);
+        catmull_rom(fx - kx, t.wx);
+        t.weight = env->layer_weight[l];
+    }
+    PhaseBuffers<T> pb{};
+    pb.opd_atm = env->as<T>(env->opd_atm);
+    pb.coefs = env->as<T>(env->coefs);
+    pb.dm_opd = env->c.dm_separable ? nullptr : env->as<T>(env->dm_opd);
+    pb.gx = env->as<T>(env->gx);
+    pb.gy = env->as<T>(env->gy);
+    pb.act_idx = env->act_idx;
+    pb.pupil = env->pupil;
+    pb.phase = env->as<T>(env->phase);
+    pb.scal = env->as<T>(env->scal);
+    pb.total = env->as<T>(env->total);
+    pb.residual = env->as<T>(env->residual);
+    pb.wfs_max = env->as<T>(env->wfs_max);
+    return launch_phase<T>(pa, pb, env->E, env->R, env->nAct, env->A, env->n_pupil, env->c.atm_wavelength,
+                           env->c.src_wavelength, st);
+}
+
+template <typename T>
+int run_wfs(AoEnv* env, hipStream_t st) {
+    if (env->c.wfs_type != AOENV_WFS_SH) return fail("wfs_type %d is not implemented in this build", env->c.wfs_type);
+    const ShConst<T> sc = sh_const<T>(env);
+    AO_TRY(launch_sh_spots<T>(env->as<T>(env->phase), sc, env->as<T>(env->frame), env->as<T>(env->wfs_max), env->E,
+                              env->R, env->nSub, env->nVal, st));
+    AO_TRY(launch_sh_centroid<T>(env->as<T>(env->frame), env->as<T>(env->wfs_max), sc, env->as<T>(env->signal), env->E,
+                                 env->R, env->nSub, env->nVal, env->c.max_group, st));
+    return 0;
+}
+
+template <typename T>
+int refresh_dense_dm(AoEnv* env, hipStream_t st) {
+    if (env->c.dm_separable) return 0;
+    return launch_gemm_nt<T>(env->as<T>(env->coefs), env->as<T>(env->modes), env->as<T>(env->dm_opd), env->E,
+                             env->R * env->R, env->A, env->A, env->A, env->R * env->R, st);
+}
+
+template <typename T>
+int run_recon(AoEnv* env, const T* d_action, T* d_obs, T* d_reward, int integrate, double gain, hipStream_t st) {
+    AO_TRY(launch_gemm_nt<T>(env->as<T>(env->signal), env->as<T>(env->recon), env->as<T>(env->vbuf), env->E, env->A,
+                             env->nSig, env->nSig, env->nSig, env->A, st));
+    AO_TRY(launch_recon_finish<T>(env->as<T>(env->vbuf), env->act_idx, d_action, env->as<T>(env->coefs), d_obs, d_reward,
+                                  env->E, env->nAct, env->A, env->c.leak, integrate, gain, st));
+    if (integrate) AO_TRY(refresh_dense_dm<T>(env, st));
+    return 0;
+}
+
+template <typename T>
+int step_t(AoEnv* env, int i, const void* d_action, void* d_obs, void* d_frame, void* d_reward, void* d_strehl,
+           double gain, hipStream_t st) {
+    AO_TRY(advance_atmosphere<T>(env, st));
+    AO_TRY(run_phase<T>(env, 1, i, st));
+    AO_TRY(run_wfs<T>(env, st));
+    AO_TRY(run_recon<T>(env, static_cast<const T*>(d_action), static_cast<T*>(d_obs), static_cast<T*>(d_reward), 1, gain,
+                        st));
+    if (d_strehl) AO_TRY(launch_copy_scal<T>(env->as<T>(env->scal), static_cast<T*>(d_strehl), env->E, st));
+    if (d_frame)
+        AO_HIP(hipMemcpyAsync(d_frame, env->frame, (size_t)env->E * env->c.cam_res * env->c.cam_res * sizeof(T),
+                              hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+struct BufInfo {
+    void* ptr;
+    size_t bytes;
+};
+
+int buf_info(AoEnv* env, int which, BufInfo* b) {
+    const size_t z = env->esz, E = env->E, R2 = (size_t)env->R * env->R;
+    switch (which) {
+        case AOENV_B_SCREEN: *b = {nullptr, (size_t)env->L * E * env->S * env->S * z}; return 0;   // gathered per layer
+        case AOENV_B_OPD_ATM: *b = {env->opd_atm, E * R2 * z}; return 0;
+        case AOENV_B_COEFS: *b = {env->coefs, E * env->A * z}; return 0;
+        case AOENV_B_PHASE: *b = {env->phase, E * R2 * z}; return 0;
+        case AOENV_B_FRAME: *b = {env->frame, E * (size_t)env->c.cam_res * env->c.cam_res * z}; return 0;
+        case AOENV_B_SIGNAL: *b = {env->signal, E * env->nSig * z}; return 0;
+        case AOENV_B_TOTAL: *b = {env->total, (size_t)env->c.n_loop * E * z}; return 0;
+        case AOENV_B_RESIDUAL: *b = {env->residual, (size_t)env->c.n_loop * E * z}; return 0;
+        case AOENV_B_WFS_MAX: *b = {env->wfs_max, E * z}; return 0;
+        case AOENV_B_XI: *b = {env->zx, E * env->K * z}; return 0;
+        default: return fail("unknown buffer id %d", which);
+    }
+}
+
+}  // namespace
+
+#define AO_CHECK_ENV(env)                         \
+    do {                                          \
+        if (!(env)) return fail("null AoEnv");    \
+        AO_HIP(hipSetDevice((env)->device));      \
+    } while (0)
+#define AO_DISPATCH(env, fn, ...) ((env)->c.dtype == AOENV_F32 ? fn<float>(__VA_ARGS__) : fn<double>(__VA_ARGS__))
+
+extern "C" {
+
+const char* aoenv_last_error(void) { return g_err.c_str(); }
+int aoenv_abi_version(void) { return AOENV_ABI_VERSION; }
+
+int aoenv_create(const AoCfg* cfg, int device, AoEnv** out) {
+    if (!cfg || !out) return fail("aoenv_create: null argument");
+    if (cfg->abi_version != AOENV_ABI_VERSION) return fail("ABI version %d != %d", cfg->abi_version, AOENV_ABI_VERSION);
+    if (cfg->dtype != AOENV_F32 && cfg->dtype != AOENV_F64) return fail("bad dtype %d", cfg->dtype);
+    if (cfg->n_env < 1 || cfg->resolution < 2) return fail("bad n_env / resolution");
+    if (cfg->n_layer < 0 || cfg->n_layer > kMaxLayer) return fail("n_layer %d out of range [0, %d]", cfg->n_layer, kMaxLayer);
+    if (cfg->n_subap < 1 || cfg->resolution % cfg->n_subap) return fail("resolution %% n_subap != 0");
+    if (cfg->n_layer > 0) {
+        if (cfg->layer_res < cfg->resolution + 4) return fail("layer_res %d < R + 4", cfg->layer_res);
+        if (cfg->n_inner != 8 * cfg->layer_res - 16 || cfg->n_outer != 4 * cfg->layer_res + 4)
+            return fail("n_inner / n_outer do not match layer_res");
+    }
+    if (cfg->wfs_type == AOENV_WFS_SH && cfg->n_signal != 2 * cfg->n_valid_subap) return fail("n_signal != 2 n_valid_subap");
+    if (cfg->max_group < 1) return fail("max_group must be >= 1");
+    int ndev = 0;
+    AO_HIP(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail("device %d not in [0, %d)", device, ndev);
+    AO_HIP(hipSetDevice(device));
+
+    AoEnv* e = new (std::nothrow) AoEnv();
+    if (!e) return fail("out of host memory");
+    e->c = *cfg;
+    e->device = device;
+    e->esz = cfg->dtype == AOENV_F32 ? 4 : 8;
+    e->R = cfg->resolution; e->N = cfg->layer_res; e->S = cfg->layer_res + 2; e->A = cfg->n_valid_act;
+    e->nAct = cfg->n_act; e->E = cfg->n_env; e->L = cfg->n_layer; e->nin = cfg->n_inner; e->nout = cfg->n_outer;
+    e->K = cfg->n_inner + cfg->n_outer; e->nSig = cfg->n_signal; e->nSub = cfg->n_subap; e->nVal = cfg->n_valid_subap;
+    e->p = e->R / e->nSub; e->n = 2 * e->p;
+    const size_t z = e->esz, E = e->E, R2 = (size_t)e->R * e->R;
+    int rc = 0;
+    auto A_ = [&](void** p, size_t bytes) { if (!rc) rc = dmalloc(e, p, bytes); };
+    if (e->L > 0) {
+        A_(&e->screen[0], (size_t)e->L * E * e->S * e->S * z);
+        A_(&e->screen[1], (size_t)e->L * E * e->S * e->S * z);
+        A_(&e->minmax, (size_t)e->L * E * 2 * z);
+        A_((void**)&e->mt_state, (size_t)e->L * E * kMtN * 4);
+        A_((void**)&e->mt_pos, (size_t)e->L * E * 4);
+        A_(&e->zx, E * e->K * z);
+        A_(&e->xbuf, E * e->nout * z);
+        A_(&e->ab, (size_t)e->nout * e->K * z);
+        A_((void**)&e->inner_idx, (size_t)e->nin * 4);
+        A_((void**)&e->outer_idx, (size_t)e->nout * 4);
+    }
+    A_(&e->gx, (size_t)e->R * e->nAct * z);
+    A_(&e->gy, (size_t)e->R * e->nAct * z);
+    if (!cfg->dm_separable) {
+        A_(&e->modes, R2 * e->A * z);
+        A_(&e->dm_opd, E * R2 * z);
+    }
+    A_((void**)&e->act_idx, (size_t)e->A * 4);
+    A_((void**)&e->pupil, R2);
+    A_(&e->opd_atm, E * R2 * z);
+    A_(&e->coefs, E * e->A * z);
+    A_(&e->phase, E * R2 * z);
+    A_(&e->scal, E * 4 * z);
+    A_(&e->total, (size_t)cfg->n_loop * E * z);
+    A_(&e->residual, (size_t)cfg->n_loop * E * z);
+    A_(&e->wfs_max, E * z);
+    A_(&e->amp, R2 * z);
+    A_((void**)&e->subap_idx, (size_t)e->nVal * 4);
+    A_(&e->sh_ref, (size_t)2 * e->nVal * z);
+    A_(&e->tw, (size_t)e->n * 2 * z);
+    A_(&e->phs, (size_t)e->p * 2 * z);
+    A_(&e->frame, E * (size_t)cfg->cam_res * cfg->cam_res * z);
+    A_(&e->signal, E * e->nSig * z);
+    A_(&e->recon, (size_t)e->A * e->nSig * z);
+    A_(&e->vbuf, E * e->A * z);
+    A_(&e->obs_scratch, E * (size_t)e->nAct * e->nAct * z);
+    if (rc) { aoenv_destroy(e); return rc; }
+
+    // DFT twiddles w^k = exp(-2 pi i k / n) and the centring phasor exp(-i pi (n+1)/n x) at x = a + lo
+    // (OOPAO/ShackHartmann.py:208-209), in float64 then converted
+    if (cfg->wfs_type == AOENV_WFS_SH) {
+        const int n = e->n, p = e->p, lo = n / 2 - p / 2;
+        std::vector<double> tw(2 * n), ph(2 * p);
+        const double pi = 3.14159265358979323846;
+        for (int k = 0; k < n; ++k) { tw[2 * k] = std::cos(2 * pi * k / n); tw[2 * k + 1] = -std::sin(2 * pi * k / n); }
+        for (int a = 0; a < p; ++a) {
+            const double ang = pi * (n + 1) / n * (a + lo);
+            ph[2 * a] = std::cos(ang); ph[2 * a + 1] = -std::sin(ang);
+        }
+        rc = upload_real(e, e->tw, tw.data(), tw.size());
+        if (!rc) rc = upload_real(e, e->phs, ph.data(), ph.size());
+        if (rc) { aoenv_destroy(e); return rc; }
+    }
+    *out = e;
+    return 0;
+}
+
+int aoenv_destroy(AoEnv* env) {
+    if (!env) return 0;
+    hipSetDevice(env->device);
+    for (void* p : env->allocs) hipFree(p);
+    delete env;
+    return 0;
+}
+
+int aoenv_upload(AoEnv* env, int kind, const void* h, size_t bytes) {
+    AO_CHECK_ENV(env);
+    if (!h) return fail("aoenv_upload: null data");
+    const size_t R2 = (size_t)env->R * env->R;
+    auto need = [&](size_t n) { return bytes == n ? 0 : fail("aoenv_upload(kind=%d): got %zu bytes, expected %zu", kind, bytes, n); };
+    const double* d = static_cast<const double*>(h);
+    switch (kind) {
+        case AOENV_C_PUPIL: {
+            AO_TRY(need(R2));
+            AO_HIP(hipMemcpy(env->pupil, h, R2, hipMemcpyHostToDevice));
+            const uint8_t* pu = static_cast<const uint8_t*>(h);
+            env->n_pupil = 0;
+            for (size_t i = 0; i < R2; ++i) env->n_pupil += pu[i] != 0;
+            break;
+        }
+        case AOENV_C_AB:
+            if (env->L == 0) return fail("no atmosphere in this shard");
+            AO_TRY(need((size_t)env->nout * env->K * 8));
+            AO_TRY(upload_real(env, env->ab, d, (size_t)env->nout * env->K));
+            break;
+        case AOENV_C_INNER_IDX:
+        case AOENV_C_OUTER_IDX: {
+            if (env->L == 0) return fail("no atmosphere in this shard");
+            const int cnt = kind == AOENV_C_INNER_IDX ? env->nin : env->nout;
+            AO_TRY(need((size_t)cnt * 4));
+            const int32_t* ix = static_cast<const int32_t*>(h);
+            for (int i = 0; i < cnt; ++i)
+                if (ix[i] < 0 || ix[i] >= env->S * env->S) return fail("ring index %d out of the %dx%d screen", ix[i], env->S, env->S);
+            if (kind == AOENV_C_INNER_IDX)          // the gather reads idx - sy*S - sx with |s| <= 1
+                for (int i = 0; i < cnt; ++i) {
+                    const int r = ix[i] / env->S, c = ix[i] % env->S;
+                    if (r < 1 || r > env->N || c < 1 || c > env->N) return fail("inner ring index %d is not interior", ix[i]);
+                }
+            AO_HIP(hipMemcpy(kind == AOENV_C_INNER_IDX ? env->inner_idx : env->outer_idx, h, (size_t)cnt * 4, hipMemcpyHostToDevice));
+            break;
+        }
+        case AOENV_C_LAYER_WEIGHT:
+            AO_TRY(need((size_t)env->L * 8));
+            for (int l = 0; l < env->L; ++l) env->layer_weight[l] = d[l];
+            break;
+        case AOENV_C_DM_GX:
+        case AOENV_C_DM_GY:
+            AO_TRY(need((size_t)env->R * env->nAct * 8));
+            AO_TRY(upload_real(env, kind == AOENV_C_DM_GX ? env->gx : env->gy, d, (size_t)env->R * env->nAct));
+            break;
+        case AOENV_C_DM_MODES:
+            if (env->c.dm_separable) return fail("dense modes uploaded to a separable-DM shard");
+            AO_TRY(need(R2 * env->A * 8));
+            AO_TRY(upload_real(env, env->modes, d, R2 * env->A));
+            break;
+        case AOENV_C_ACT_IDX: {
+            AO_TRY(need((size_t)env->A * 4));
+            const int32_t* ix = static_cast<const int32_t*>(h);
+            for (int i = 0; i < env->A; ++i)
+                if (ix[i] < 0 || ix[i] >= env->nAct * env->nAct) return fail("actuator index %d out of range", ix[i]);
+            AO_HIP(hipMemcpy(env->act_idx, h, (size_t)env->A * 4, hipMemcpyHostToDevice));
+            break;
+        }
+        case AOENV_C_WFS_AMP:
+            AO_TRY(need(R2 * 8));
+            AO_TRY(upload_real(env, env->amp, d, R2));
+            break;
+        case AOENV_C_SH_SUBAP_IDX: {
+            AO_TRY(need((size_t)env->nVal * 4));
+            const int32_t* ix = static_cast<const int32_t*>(h);
+            for (int i = 0; i < env->nVal; ++i)
+                if (ix[i] < 0 || ix[i] >= env->nSub * env->nSub) return fail("lenslet index %d out of range", ix[i]);
+            AO_HIP(hipMemcpy(env->subap_idx, h, (size_t)env->nVal * 4, hipMemcpyHostToDevice));
+            break;
+        }
+        case AOENV_C_SH_REF:
+            AO_TRY(need((size_t)2 * env->nVal * 8));
+            AO_TRY(upload_real(env, env->sh_ref, d, (size_t)2 * env->nVal));
+            break;
+        case AOENV_C_WFS_UNITS:
+            AO_TRY(need(8));
+            if (!(d[0] != 0)) return fail("slopes units must be non-zero");
+            env->units = d[0];
+            break;
+        case AOENV_C_RECON:
+            AO_TRY(need((size_t)env->A * env->nSig * 8));
+            AO_TRY(upload_real(env, env->recon, d, (size_t)env->A * env->nSig));
+            break;
+        default: return fail("unknown constant id %d", kind);
+    }
+    env->have[kind] = true;
+    return 0;
+}
+
+int aoenv_set_wind(AoEnv* env, const double* h_ratio, int reset_buff) {
+    AO_CHECK_ENV(env);
+    if (!h_ratio) return fail("null ratio");
+    for (int l = 0; l < env->L; ++l) {
+        env->clk[l].ratio[0] = h_ratio[2 * l];
+        env->clk[l].ratio[1] = h_ratio[2 * l + 1];
+        if (reset_buff) env->clk[l].buff[0] = env->clk[l].buff[1] = 0;
+    }
+    return 0;
+}
+
+static int require_step_constants(AoEnv* env, bool atmosphere) {
+    static const int base[] = {AOENV_C_PUPIL, AOENV_C_ACT_IDX, AOENV_C_WFS_AMP, AOENV_C_SH_SUBAP_IDX};
+    for (int k : base)
+        if (!env->have[k]) return fail("constant table %d has not been uploaded", k);
+    if (env->c.dm_separable ? !(env->have[AOENV_C_DM_GX] && env->have[AOENV_C_DM_GY]) : !env->have[AOENV_C_DM_MODES])
+        return fail("DM influence functions have not been uploaded");
+    if (atmosphere && env->L > 0)
+        for (int k : {AOENV_C_AB, AOENV_C_INNER_IDX, AOENV_C_OUTER_IDX, AOENV_C_LAYER_WEIGHT})
+            if (!env->have[k]) return fail("atmosphere table %d has not been uploaded", k);
+    return 0;
+}
+
+int aoenv_new_screens(AoEnv* env, const double* h_screens, const uint32_t* h_ring_seeds, void* stream) {
+    AO_CHECK_ENV(env);
+    if (env->L == 0) return fail("no atmosphere in this shard");
+    AO_TRY(require_step_constants(env, true));
+    if (!h_ring_seeds) return fail("null ring seeds");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    AO_HIP(hipStreamSynchronize(st));
+    const int E = env->E, L = env->L, N = env->N, S = env->S;
+    if (h_screens) {
+        // mapShift[~outerMask] = phase  (OOPAO/Atmosphere.py:585); the ring is drawn below
+        std::vector<char> host((size_t)E * S * S * env->esz);
+        for (int l = 0; l < L; ++l) {
+            std::memset(host.data(), 0, host.size());
+            for (int e = 0; e < E; ++e) {
+                const double* src = h_screens + ((size_t)e * L + l) * N * N;
+                for (int r = 0; r < N; ++r)
+                    for (int c = 0; c < N; ++c) {
+                        const size_t o = (size_t)e * S * S + (size_t)(r + 1) * S + (c + 1);
+                        if (env->esz == 4) reinterpret_cast<float*>(host.data())[o] = (float)src[(size_t)r * N + c];
+                        else reinterpret_cast<double*>(host.data())[o] = src[(size_t)r * N + c];
+                    }
+            }
+            AO_HIP(hipMemcpy(env->screen_ptr(env->cur[l], l), host.data(), host.size(), hipMemcpyHostToDevice));
+        }
+    }
+    std::vector<uint32_t> keys((size_t)L * E * kMtN);
+    std::vector<int> pos((size_t)L * E, kMtN);
+    for (int l = 0; l < L; ++l)
+        for (int e = 0; e < E; ++e) mt_seed(h_ring_seeds[(size_t)e * L + l], &keys[((size_t)l * E + e) * kMtN]);
+    AO_HIP(hipMemcpy(env->mt_state, keys.data(), keys.size() * 4, hipMemcpyHostToDevice));
+    AO_HIP(hipMemcpy(env->mt_pos, pos.data(), pos.size() * 4, hipMemcpyHostToDevice));
+    for (int l = 0; l < L; ++l) {
+        env->clk[l].buff[0] = env->clk[l].buff[1] = 0;            // notDoneOnce (OOPAO/Atmosphere.py:586, 359-364)
+        AO_TRY(AO_DISPATCH(env, extrude, env, l, 0, 0, false, st));
+    }
+    AO_TRY(AO_DISPATCH(env, run_phase, env, 1, -1, st));           // fill_phase_support + set_OPD + atm*tel
+    return 0;
+}
+
+int aoenv_set_atm_opd(AoEnv* env, const double* h_opd, void* stream) {
+    AO_CHECK_ENV(env);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    AO_HIP(hipStreamSynchronize(st));
+    const size_t n = (size_t)env->E * env->R * env->R;
+    if (!h_opd) { AO_HIP(hipMemset(env->opd_atm, 0, n * env->esz)); return 0; }
+    return upload_real(env, env->opd_atm, h_opd, n);
+}
+
+int aoenv_set_coefs(AoEnv* env, const double* h_coefs, void* stream) {
+    AO_CHECK_ENV(env);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    AO_HIP(hipStreamSynchronize(st));
+    const size_t n = (size_t)env->E * env->A;
+    if (!h_coefs) AO_HIP(hipMemset(env->coefs, 0, n * env->esz));
+    else AO_TRY(upload_real(env, env->coefs, h_coefs, n));
+    return AO_DISPATCH(env, refresh_dense_dm, env, st);
+}
+
+int aoenv_measure(AoEnv* env, void* stream) {
+    AO_CHECK_ENV(env);
+    AO_TRY(require_step_constants(env, false));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    AO_TRY(AO_DISPATCH(env, run_phase, env, 0, -1, st));
+    return AO_DISPATCH(env, run_wfs, env, st);
+}
+
+int aoenv_reset_soft(AoEnv* env, void* d_obs, void* stream) {
+    AO_CHECK_ENV(env);
+    if (!d_obs) return fail("null obs");
+    if (!env->have[AOENV_C_RECON]) return fail("the reconstructor has not been uploaded");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (env->c.dtype == AOENV_F32) return run_recon<float>(env, nullptr, static_cast<float*>(d_obs), nullptr, 0, 0.0, st);
+    return run_recon<double>(env, nullptr, static_cast<double*>(d_obs), nullptr, 0, 0.0, st);
+}
+
+int aoenv_step(AoEnv* env, int i, const void* d_action, void* d_obs, void* d_frame, void* d_reward, void* d_strehl,
+               void* stream) {
+    AO_CHECK_ENV(env);
+    if (!d_action || !d_obs) return fail("aoenv_step: null action / obs");
+    if (i < 0 || i >= env->c.n_loop) return fail("frame index %d outside [0, n_loop=%d)", i, env->c.n_loop);
+    AO_TRY(require_step_constants(env, true));
+    if (!env->have[AOENV_C_RECON]) return fail("the reconstructor has not been uploaded");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    return AO_DISPATCH(env, step_t, env, i, d_action, d_obs, d_frame, d_reward, d_strehl, 0.0, st);
+}
+
+int aoenv_run_integrator(AoEnv* env, int i0, int n_steps, double gain, void* d_obs, void* d_frame, void* d_reward,
+                         void* d_strehl, void* stream) {
+    AO_CHECK_ENV(env);
+    if (!d_obs) return fail("aoenv_run_integrator: null obs");
+    if (gain == 0) return fail("aoenv_run_integrator: gain must be non-zero");
+    if (i0 < 0 || n_steps < 0 || i0 + n_steps > env->c.n_loop) return fail("frames [%d, %d) outside [0, n_loop=%d)", i0, i0 + n_steps, env->c.n_loop);
+    AO_TRY(require_step_constants(env, true));
+    if (!env->have[AOENV_C_RECON]) return fail("the reconstructor has not been uploaded");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (int k = 0; k < n_steps; ++k)
+        AO_TRY(AO_DISPATCH(env, step_t, env, i0 + k, d_obs /*unused*/, d_obs, k == n_steps - 1 ? d_frame : nullptr, d_reward,
+                           d_strehl, gain, st));
+    return 0;
+}
+
+int aoenv_buffer(AoEnv* env, int which, void** d_ptr, size_t* bytes) {
+    AO_CHECK_ENV(env);
+    BufInfo b{};
+    AO_TRY(buf_info(env, which, &b));
+    if (which == AOENV_B_SCREEN) return fail("the screens are a ping-pong pair: use aoenv_download / aoenv_upload_state");
+    if (d_ptr) *d_ptr = b.ptr;
+    if (bytes) *bytes = b.bytes;
+    return 0;
+}
+
+int aoenv_download(AoEnv* env, int which, void* h_dst, size_t bytes, void* stream) {
+    AO_CHECK_ENV(env);
+    BufInfo b{};
+    AO_TRY(buf_info(env, which, &b));
+    if (bytes != b.bytes) return fail("aoenv_download(%d): got %zu bytes, expected %zu", which, bytes, b.bytes);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    AO_HIP(hipStreamSynchronize(st));
+    if (which == AOENV_B_SCREEN) {
+        const size_t per = (size_t)env->E * env->S * env->S * env->esz;
+        for (int l = 0; l < env->L; ++l)
+            AO_HIP(hipMemcpy(static_cast<char*>(h_dst) + l * per, env->screen_ptr(env->cur[l], l), per, hipMemcpyDeviceToHost));
+        return 0;
+    }
+    AO_HIP(hipMemcpy(h_dst, b.ptr, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int aoenv_upload_state(AoEnv* env, int which, const void* h_src, size_t bytes, void* stream) {
+    AO_CHECK_ENV(env);
+    BufInfo b{};
+    AO_TRY(buf_info(env, which, &b));
+    if (bytes != b.bytes) return fail("aoenv_upload_state(%d): got %zu bytes, expected %zu", which, bytes, b.bytes);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    AO_HIP(hipStreamSynchronize(st));
+    if (which == AOENV_B_SCREEN) return fail("screen upload is not implemented (it also needs the min/max table)");
+    AO_HIP(hipMemcpy(b.ptr, h_src, bytes, hipMemcpyHostToDevice));
+    if (which == AOENV_B_COEFS) return AO_DISPATCH(env, refresh_dense_dm, env, st);
+    return 0;
+}
+
+int aoenv_get_buff(AoEnv* env, double* h_buff) {
+    if (!env || !h_buff) return fail("null argument");
+    for (int l = 0; l < env->L; ++l) { h_buff[2 * l] = env->clk[l].buff[0]; h_buff[2 * l + 1] = env->clk[l].buff[1]; }
+    return 0;
+}
+
+int aoenv_set_buff(AoEnv* env, const double* h_buff) {
+    if (!env || !h_buff) return fail("null argument");
+    for (int l = 0; l < env->L; ++l) {
+        if (std::fabs(h_buff[2 * l]) >= 1 || std::fabs(h_buff[2 * l + 1]) >= 1) return fail("|buff| must be < 1");
+        env->clk[l].buff[0] = h_buff[2 * l]; env->clk[l].buff[1] = h_buff[2 * l + 1];
+    }
+    return 0;
+}
+
+int aoenv_test_normal(int device, uint32_t seed, int n, int n_calls, double* h_out) {
+    if (n < 2 || n % 2 || n_calls < 1 || !h_out) return fail("aoenv_test_normal: bad arguments");
+    AO_HIP(hipSetDevice(device));
+    uint32_t* st = nullptr; int* pos = nullptr; double* zx = nullptr;
+    std::vector<uint32_t> key(kMtN);
+    mt_seed(seed, key.data());
+    int p0 = kMtN;
+    AO_HIP(hipMalloc((void**)&st, kMtN * 4));
+    AO_HIP(hipMalloc((void**)&pos, 4));
+    AO_HIP(hipMalloc((void**)&zx, (size_t)n * 8));
+    AO_HIP(hipMemcpy(st, key.data(), kMtN * 4, hipMemcpyHostToDevice));
+    AO_HIP(hipMemcpy(pos, &p0, 4, hipMemcpyHostToDevice));
+    int rc = 0;
+    for (int c = 0; c < n_calls && !rc; ++c) {
+        rc = launch_mt_normal<double>(st, pos, zx, 1, n, 0, n, nullptr);
+        if (!rc && hipMemcpy(h_out + (size_t)c * n, zx, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = fail("copy back failed");
+    }
+    hipFree(st); hipFree(pos); hipFree(zx);
+    return rc;
+}
+
+}  // extern "C"

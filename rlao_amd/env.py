@@ -1,0 +1,622 @@
+"""BatchedAOEnv: the gym-style surface of drl4ao's OOPAO environment, N loops per GPU, on libaoenv.
+
+Mirrors ``MAIN/OOPAOEnv/OOPAOEnv.py`` (class ``OOPAO``): ``set_params_file / set_params / reset_soft /
+step(i, action) / sample_noise / vec_to_img / img_to_vec / calculate_strehl_AVG / get_strehl`` and the
+attributes and reach-through objects the trainers touch (``env.atm.generateNewPhaseScreen``,
+``env.dm.coefs = 0``, ``env.tel*env.dm*env.wfs``, ``env.wfs.cam.frame`` ... -- MAIN/PO4AO/mbrl.py:49-52,
+MAIN/integrator_oopao_razor.py:36-91).
+
+All per-step physics runs in the HIP library; this module only owns PyTorch tensors for I/O and the
+one-off calibration driver.  There is no CPU path: constructing an env without a GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from concurrent.futures import ThreadPoolExecutor
+from types import SimpleNamespace
+
+import numpy as np
+
+from . import _lib as L
+from . import calib
+
+_NP_DT = {"f32": np.float32, "f64": np.float64}
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class Shard:
+    """One AoEnv handle of libaoenv (a shard of independent loops on one GPU)."""
+
+    def __init__(self, cfg: dict, device: int):
+        self.lib = L.load()
+        self.cfg = L.AoCfg(abi_version=L.ABI_VERSION, pyr_n_res=0, pyr_n_theta=1, **cfg)
+        self.device = device
+        self.np_dtype = np.float32 if cfg["dtype"] == L.F32 else np.float64
+        h = C.c_void_p()
+        L.check(self.lib.aoenv_create(C.byref(self.cfg), device, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.aoenv_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def upload(self, kind: int, arr: np.ndarray):
+        want = {L.C_PUPIL: np.uint8, L.C_INNER_IDX: np.int32, L.C_OUTER_IDX: np.int32, L.C_ACT_IDX: np.int32,
+                L.C_SH_SUBAP_IDX: np.int32}.get(kind, np.float64)
+        a = np.ascontiguousarray(arr, dtype=want)
+        L.check(self.lib.aoenv_upload(self.h, kind, a.ctypes.data_as(C.c_void_p), a.nbytes))
+
+    def set_wind(self, ratio: np.ndarray, reset_buff: bool):
+        r = np.ascontiguousarray(ratio, dtype=np.float64)
+        L.check(self.lib.aoenv_set_wind(self.h, r.ctypes.data_as(C.c_void_p), int(reset_buff)))
+
+    def new_screens(self, screens, ring_seeds, stream=0):
+        s = None if screens is None else np.ascontiguousarray(screens, dtype=np.float64)
+        k = np.ascontiguousarray(ring_seeds, dtype=np.uint32)
+        L.check(self.lib.aoenv_new_screens(self.h, None if s is None else s.ctypes.data_as(C.c_void_p),
+                                           k.ctypes.data_as(C.c_void_p), C.c_void_p(stream)))
+
+    def set_atm_opd(self, opd, stream=0):
+        a = None if opd is None else np.ascontiguousarray(opd, dtype=np.float64)
+        L.check(self.lib.aoenv_set_atm_opd(self.h, None if a is None else a.ctypes.data_as(C.c_void_p), C.c_void_p(stream)))
+
+    def set_coefs(self, coefs, stream=0):
+        a = None if coefs is None else np.ascontiguousarray(coefs, dtype=np.float64)
+        L.check(self.lib.aoenv_set_coefs(self.h, None if a is None else a.ctypes.data_as(C.c_void_p), C.c_void_p(stream)))
+
+    def measure(self, stream=0):
+        L.check(self.lib.aoenv_measure(self.h, C.c_void_p(stream)))
+
+    def download(self, which: int, shape, stream=0) -> np.ndarray:
+        out = np.empty(shape, dtype=self.np_dtype)
+        L.check(self.lib.aoenv_download(self.h, which, out.ctypes.data_as(C.c_void_p), out.nbytes, C.c_void_p(stream)))
+        return out
+
+    def upload_state(self, which: int, arr, stream=0):
+        a = np.ascontiguousarray(arr, dtype=self.np_dtype)
+        L.check(self.lib.aoenv_upload_state(self.h, which, a.ctypes.data_as(C.c_void_p), a.nbytes, C.c_void_p(stream)))
+
+    def get_buff(self, n_layer: int) -> np.ndarray:
+        out = np.zeros((max(n_layer, 1), 2))
+        L.check(self.lib.aoenv_get_buff(self.h, out.ctypes.data_as(C.c_void_p)))
+        return out[:n_layer]
+
+    def set_buff(self, buff):
+        b = np.ascontiguousarray(buff, dtype=np.float64)
+        L.check(self.lib.aoenv_set_buff(self.h, b.ctypes.data_as(C.c_void_p)))
+
+
+# ----------------------------------------------------------------------------------------------------
+# reach-through proxies (only the uses listed in SURVEY.md 8b)
+# ----------------------------------------------------------------------------------------------------
+class _AtmProxy:
+    tag = "atmosphere"
+
+    def __init__(self, env):
+        self._e = env
+
+    @property
+    def windSpeed(self):
+        return list(self._e.param.windSpeed)
+
+    @windSpeed.setter
+    def windSpeed(self, val):
+        """OOPAO/Atmosphere.py:829-847: new ratio, the sub-pixel accumulator is kept."""
+        e = self._e
+        if len(val) != e.param.nLayer:
+            print("Error! Wrong value for the wind-speed! Make sure that you inpute a wind-speed for each layer")
+            return
+        e.param.windSpeed = [float(v) for v in val]
+        e._push_wind(reset=False)
+
+    @property
+    def windDirection(self):
+        return list(self._e.param.windDirection)
+
+    @windDirection.setter
+    def windDirection(self, val):
+        e = self._e
+        if len(val) != e.param.nLayer:
+            print("Error! Wrong value for the wind-speed! Make sure that you inpute a wind-speed for each layer")
+            return
+        e.param.windDirection = [float(v) for v in val]
+        e._push_wind(reset=False)
+
+    @property
+    def r0(self):
+        return self._e.param.r0
+
+    @r0.setter
+    def r0(self, val):
+        """OOPAO/Atmosphere.py:792-807: rescales the covariances; only B changes (A is r0-invariant)."""
+        e = self._e
+        e.param.r0 = float(val)
+        e._atm_tables.set_r0(e.param.r0)
+        e._shard.upload(L.C_AB, e._atm_tables.AB)
+
+    @property
+    def nLayer(self):
+        return self._e.param.nLayer
+
+    def generateNewPhaseScreen(self, seed=None):
+        self._e.generate_new_phase_screen(seed)
+
+    def update(self):
+        raise NotImplementedError("atm.update() outside env.step() is not part of the hot-path surface")
+
+    @property
+    def OPD_no_pupil(self):
+        return self._e._fetch(L.B_OPD_ATM, (self._e.R, self._e.R))
+
+    @property
+    def OPD(self):
+        return self.OPD_no_pupil * self._e.pupil
+
+
+class _DmProxy:
+    tag = "deformableMirror"
+
+    def __init__(self, env):
+        self._e = env
+
+    @property
+    def nValidAct(self):
+        return self._e.nValidAct
+
+    @property
+    def coefs(self):
+        return self._e._fetch(L.B_COEFS, (self._e.nValidAct,))
+
+    @coefs.setter
+    def coefs(self, val):
+        e = self._e
+        if np.isscalar(val):
+            if val != 0:
+                print("Error: wrong value for the coefficients")
+                return
+            e._shard.set_coefs(None, e._stream())
+            return
+        v = np.asarray(val, dtype=np.float64)
+        if v.shape == (e.nValidAct,):
+            v = np.broadcast_to(v, (e.n_envs, e.nValidAct))
+        if v.shape != (e.n_envs, e.nValidAct):
+            raise ValueError(f"coefs must have shape ({e.nValidAct},) or ({e.n_envs}, {e.nValidAct})")
+        e._shard.set_coefs(v, e._stream())
+
+    @property
+    def modes(self):
+        return self._e._dm_tables.dense_modes()
+
+
+class _Cam:
+    def __init__(self, env):
+        self._e = env
+        self.photonNoise = False
+        self.readoutNoise = 0
+
+    @property
+    def frame(self):
+        return self._e._fetch(L.B_FRAME, (self._e.cam_res, self._e.cam_res))
+
+
+class _WfsProxy:
+    def __init__(self, env):
+        self._e = env
+        self.tag = "shackHartmann"
+        self.cam = _Cam(env)
+
+    @property
+    def nSignal(self):
+        return self._e.nSignal
+
+    @property
+    def signal(self):
+        return self._e._fetch(L.B_SIGNAL, (self._e.nSignal,))
+
+
+class _TelProxy:
+    """``env.tel*env.dm*env.wfs`` (MAIN/PO4AO/mbrl.py:52): DM propagation then one WFS measurement."""
+    tag = "telescope"
+
+    def __init__(self, env):
+        self._e = env
+        self.PSF = None
+
+    @property
+    def resolution(self):
+        return self._e.R
+
+    @property
+    def D(self):
+        return self._e.param.diameter
+
+    @property
+    def pupil(self):
+        return self._e.pupil.astype(int)
+
+    @property
+    def samplingTime(self):
+        return self._e.param.samplingTime
+
+    def __mul__(self, obj):
+        if getattr(obj, "tag", None) == "deformableMirror":
+            return self
+        if getattr(obj, "tag", None) in ("shackHartmann", "pyramid"):
+            self._e.measure()
+            return self
+        raise AttributeError("the telescope can be multiplied only with the DM and the WFS of this env")
+
+    def resetOPD(self):
+        """Flat wave-front for a telescope that is not paired to the atmosphere (OOPAO/Telescope.py:566-579);
+        the batched env is always paired and re-derives its OPD from the screens on the next step."""
+        return None
+
+    @property
+    def OPD(self):
+        e = self._e
+        return e._fetch(L.B_PHASE, (e.R, e.R)) * (e.src_wavelength / (2 * np.pi))
+
+    def computePSF(self, zeroPaddingFactor=2):
+        raise NotImplementedError("the science-path PSF is SURVEY.md row f2 (next), not part of the step hot path")
+
+
+# ----------------------------------------------------------------------------------------------------
+class BatchedAOEnv:
+    """N independent closed AO loops on one GPU behind drl4ao's ``OOPAO`` env surface.
+
+    ``output='torch'`` (default): device tensors with a leading N dimension.
+    ``output='numpy'`` with ``n_envs == 1``: the reference's exact return types, so the stock
+    ``TorchWrapper`` / trainers run unchanged.
+    """
+
+    metadata = {"render.modes": ["rgb_array"]}
+
+    def __init__(self, n_envs: int = 1, device=None, dtype: str = "f32", output: str = "torch",
+                 return_frame: bool = True, env_seed_stride: int = 1, env_index_offset: int = 0):
+        if dtype not in _NP_DT:
+            raise ValueError("dtype must be 'f32' or 'f64'")
+        if output not in ("torch", "numpy"):
+            raise ValueError("output must be 'torch' or 'numpy'")
+        if output == "numpy" and n_envs != 1:
+            raise ValueError("output='numpy' reproduces the single-env reference interface: n_envs must be 1")
+        L.load()                                  # no CPU fallback: fail here if the HIP library is missing
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise L.AoEnvError("BatchedAOEnv needs a ROCm GPU: the step path exists only as HIP kernels")
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        if isinstance(device, str):
+            device = torch.device(device).index or 0
+        if isinstance(device, torch.device):
+            device = device.index or 0
+        self.device_index = int(device)
+        self.device = torch.device("cuda", self.device_index)
+        self.n_envs = int(n_envs)
+        self.dtype = dtype
+        self.tdtype = torch.float32 if dtype == "f32" else torch.float64
+        self.output = output
+        self.return_frame = return_frame
+        self.env_seed_stride = int(env_seed_stride)
+        self.env_index_offset = int(env_index_offset)
+        # attributes of the reference env (MAIN/OOPAOEnv/OOPAOEnv.py:19-72)
+        self.gainCL = None
+        self.net_gain = 0.5
+        self.leak = 0.99
+        self.delay = 1
+        self.F = 1
+        self.reconstructor = None
+        self.nActuator = None
+        self.xvalid = self.yvalid = None
+        self.dm_mask = None
+        self.SR = []
+        self.LE_PSF = None
+        self.name = "OOPAO"
+        self.param_file = ""
+        self.oopao_path = ""
+        self.action_buffer = []
+        self.atm = self.dm = self.tel = self.wfs = None
+        self._shard = None
+
+    # -- construction --------------------------------------------------------------------------------
+    def set_params_file(self, param_file, oopao_path):
+        """Kept for call compatibility (MAIN/PO4AO/mbrl.py:27); the parameters come from ``set_params``."""
+        self.param_file, self.oopao_path = param_file, oopao_path
+
+    def set_params(self, args=None, wfs_type="shackhartmann", modal_basis="zernike", gainCL=0.5, m2c=None, **kw):
+        if wfs_type not in ("shackhartmann", "sh"):
+            raise NotImplementedError("only the Shack-Hartmann WFS is built so far (Pyramid: SURVEY.md K5)")
+        torch = _torch()
+        self.gainCL = gainCL
+        p = self.param = calib.params_from_args(args, **kw)
+        self.leak = p.leak
+        self.R = p.resolution
+        self.pupil = calib.telescope_pupil(self.R, p.centralObstruction)
+        self.src_wavelength, self.nPhoton = calib.source(p.opticalBand, p.magnitude)
+        self._atm_tables = calib.AtmosphereTables(p)
+        self._dm_tables = dmt = calib.DMTables(p)
+        self._sh_tables = sht = calib.SHTables(p, self.pupil, self.nPhoton)
+        self.nActuator, self.nValidAct = dmt.nAct, dmt.nValidAct
+        self.dm_mask = dmt.dm_mask.astype(int)
+        self.xvalid, self.yvalid = dmt.xvalid, dmt.yvalid
+        self.nSignal, self.cam_res = sht.nSignal, sht.cam_res
+        self._xv_t = torch.as_tensor(self.xvalid, device=self.device)
+        self._yv_t = torch.as_tensor(self.yvalid, device=self.device)
+
+        # -- calibration on the GPU, float64, same kernels as the loop ------------------------------
+        ref, units = self._calibrate_wfs()
+        self.reference_centroids, self.slopes_units = ref, units
+        self.imat = self._interaction_matrix(ref, units)
+        if m2c is None:
+            m2c = calib.zernike_m2c(dmt, self.pupil, p.diameter, p.nModes)
+        elif isinstance(m2c, (str, os.PathLike)):
+            m2c = np.load(m2c)
+        self.M2C_CL = np.asarray(m2c, dtype=np.float64)[:, :p.nModes]
+        if self.M2C_CL.shape[0] != self.nValidAct:
+            raise ValueError(f"M2C has {self.M2C_CL.shape[0]} rows, the DM has {self.nValidAct} valid actuators")
+        self.reconstructor, self.F = calib.reconstructor_from_imat(self.imat, self.M2C_CL)
+        self._F_t = torch.as_tensor(self.F, device=self.device, dtype=self.tdtype)
+
+        # -- the loop shard -----------------------------------------------------------------------------
+        self._shard = self._make_shard(self.n_envs, self.dtype, n_layer=p.nLayer, max_group=1)
+        sh = self._shard
+        at = self._atm_tables
+        sh.upload(L.C_AB, at.AB)
+        sh.upload(L.C_INNER_IDX, at.inner_idx)
+        sh.upload(L.C_OUTER_IDX, at.outer_idx)
+        sh.upload(L.C_LAYER_WEIGHT, at.weights)
+        sh.upload(L.C_SH_REF, ref)
+        sh.upload(L.C_WFS_UNITS, np.array([units]))
+        sh.upload(L.C_RECON, self.reconstructor)
+        self._push_wind(reset=True)
+        N, A_ = self.n_envs, self.nActuator
+        self._obs = torch.zeros((N, A_, A_), device=self.device, dtype=self.tdtype)
+        self._reward = torch.zeros((N,), device=self.device, dtype=self.tdtype)
+        self._strehl = torch.zeros((N,), device=self.device, dtype=self.tdtype)
+        self._frame = torch.zeros((N, self.cam_res, self.cam_res), device=self.device, dtype=self.tdtype) \
+            if self.return_frame else None
+        self.SR = []
+        self.atm, self.dm, self.tel, self.wfs = _AtmProxy(self), _DmProxy(self), _TelProxy(self), _WfsProxy(self)
+        # flat measurement, then the initial screens (MAIN/OOPAOEnv/OOPAOEnv.py:312-322)
+        self.measure()
+        self.generate_new_phase_screen(10)
+        return self
+
+    def _make_shard(self, n_env, dtype, n_layer, max_group) -> Shard:
+        p, at, dmt, sht = self.param, self._atm_tables, self._dm_tables, self._sh_tables
+        cfg = dict(dtype=L.F32 if dtype == "f32" else L.F64, n_env=n_env, resolution=self.R, n_layer=n_layer,
+                   layer_res=at.N, n_inner=at.n_inner, n_outer=at.n_outer, n_act=dmt.nAct, n_valid_act=dmt.nValidAct,
+                   dm_separable=1, wfs_type=L.WFS_SH, n_subap=p.nSubaperture, n_valid_subap=sht.nValid,
+                   n_signal=sht.nSignal, cam_res=sht.cam_res, n_loop=int(p.nLoop), max_group=max_group,
+                   atm_wavelength=calib.ATM_WAVELENGTH, src_wavelength=self.src_wavelength, leak=p.leak,
+                   threshold_cog=p.threshold_cog)
+        sh = Shard(cfg, self.device_index)
+        sh.upload(L.C_PUPIL, self.pupil.astype(np.uint8))
+        sh.upload(L.C_DM_GX, dmt.gx)
+        sh.upload(L.C_DM_GY, dmt.gy)
+        sh.upload(L.C_ACT_IDX, dmt.act_idx)
+        sh.upload(L.C_WFS_AMP, sht.amp)
+        sh.upload(L.C_SH_SUBAP_IDX, sht.subap_idx)
+        return sh
+
+    def _calibrate_wfs(self):
+        """initialize_wfs (OOPAO/ShackHartmann.py:254-312): reference centroids from a flat wave-front,
+        slope units from a five-point tip ramp, measured by the HIP kernels in float64."""
+        R, nv = self.R, self._sh_tables.nValid
+        cal = self._make_shard(5, "f64", n_layer=0, max_group=1)
+        try:
+            cal.upload(L.C_SH_REF, np.zeros(2 * nv))
+            cal.upload(L.C_WFS_UNITS, np.array([1.0]))
+            cal.measure()
+            ref = cal.download(L.B_SIGNAL, (5, 2 * nv))[0].astype(np.float64)
+            cal.upload(L.C_SH_REF, ref)
+            tip = calib.tip_ramp(R)
+            amp = 10e-9
+            cal.set_atm_opd(np.stack([tip * (i - 2) * amp for i in range(5)]).reshape(5, R * R))
+            cal.measure()
+            sig = cal.download(L.B_SIGNAL, (5, 2 * nv))
+            mean_slope = sig[:, :nv].mean(axis=1)
+            fit = np.polyfit(np.linspace(-2, 2, 5) * amp, mean_slope, deg=1)
+            units = float(np.abs(fit[0]) * (self.src_wavelength / 2 / np.pi))
+        finally:
+            cal.close()
+        return ref, units
+
+    def _interaction_matrix(self, ref, units):
+        """Zonal push-only interaction matrix (OOPAO/calibration/InteractionMatrix.py:13-135 with
+        single_pass=True, stroke = lambda/16, MAIN/OOPAOEnv/OOPAOEnv.py:270-288): every actuator is one
+        "env" of a float64 calibration shard; consecutive groups of nMeasurements pokes share the
+        centroid threshold as the reference's batched measurement does."""
+        A_ = self.nValidAct
+        stroke = self.src_wavelength / 16
+        cal = self._make_shard(A_, "f64", n_layer=0, max_group=int(self.param.nMeasurements))
+        try:
+            cal.upload(L.C_SH_REF, ref)
+            cal.upload(L.C_WFS_UNITS, np.array([units]))
+            cal.set_coefs(np.eye(A_) * stroke)
+            cal.measure()
+            sig = cal.download(L.B_SIGNAL, (A_, self.nSignal)).astype(np.float64)
+        finally:
+            cal.close()
+        return (sig / stroke).T                                     # [nSignal, A]
+
+    # -- plumbing ---------------------------------------------------------------------------------------
+    def _stream(self) -> int:
+        return int(_torch().cuda.current_stream(self.device).cuda_stream)
+
+    def _fetch(self, which, shape):
+        out = self._shard.download(which, (self.n_envs,) + tuple(shape), self._stream())
+        return out[0] if self.n_envs == 1 else out
+
+    def _push_wind(self, reset: bool):
+        p = self.param
+        self._shard.set_wind(self._atm_tables.wind_ratio(p.windSpeed, p.windDirection, p.samplingTime), reset)
+
+    def env_seeds(self, seed: int) -> np.ndarray:
+        idx = np.arange(self.n_envs, dtype=np.int64) + self.env_index_offset
+        return int(seed) + idx * self.env_seed_stride
+
+    def generate_new_phase_screen(self, seed=None):
+        """atm.generateNewPhaseScreen(seed) for every env; env e uses ``seed + e * env_seed_stride``
+        (layer l: screen seed + l, ring RandomState seed + 1000 l -- OOPAO/Atmosphere.py:574-579)."""
+        import time as _t
+        if seed is None:
+            t = _t.localtime()
+            seed = t.tm_hour * 3600 + t.tm_min * 60 + t.tm_sec
+        p, at = self.param, self._atm_tables
+        seeds = self.env_seeds(seed)
+        jobs = [(int(s), l) for s in seeds for l in range(p.nLayer)]
+        delta = at.layer_D / at.N
+
+        def make(job):
+            return calib.new_phase_screen(p.r0, p.L0, at.N, delta, job[0] + job[1])
+
+        if len(jobs) > 4:
+            with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+                screens = list(ex.map(make, jobs))
+        else:
+            screens = [make(j) for j in jobs]
+        screens = np.stack(screens).reshape(self.n_envs, p.nLayer, at.N * at.N)
+        ring = np.array([[(int(s) + 1000 * l) & 0xFFFFFFFF for l in range(p.nLayer)] for s in seeds], dtype=np.uint32)
+        self._shard.new_screens(screens, ring, self._stream())
+        self._push_wind(reset=True)
+
+    def measure(self):
+        """tel*dm*wfs: one WFS measurement of (atmosphere + DM), no turbulence update."""
+        self._shard.measure(self._stream())
+
+    # -- the reference surface ------------------------------------------------------------------------------
+    def _out(self, t):
+        if self.output == "numpy":
+            return t.detach().to("cpu", dtype=_torch().float64).numpy()[0]
+        return t
+
+    def reset_soft(self):
+        """MAIN/OOPAOEnv/OOPAOEnv.py:82-86."""
+        self.action_buffer = []
+        L.check(self._shard.lib.aoenv_reset_soft(self._shard.h, C.c_void_p(self._obs.data_ptr()), C.c_void_p(self._stream())))
+        return self._out(self._obs.clone())
+
+    def reset(self):
+        raise NotImplementedError("reset() re-runs set_params() with no arguments in the reference and fails there "
+                                  "(MAIN/OOPAOEnv/OOPAOEnv.py:76 vs :93); use set_params() + reset_soft()")
+
+    def _action_tensor(self, action):
+        torch = _torch()
+        a = torch.as_tensor(action)
+        if a.dim() == 2:
+            a = a.unsqueeze(0)
+        if tuple(a.shape) != (self.n_envs, self.nActuator, self.nActuator):
+            raise ValueError(f"action must have shape ({self.n_envs}, {self.nActuator}, {self.nActuator}), got {tuple(a.shape)}")
+        return a.to(device=self.device, dtype=self.tdtype).contiguous()
+
+    def step(self, i, action):
+        """MAIN/OOPAOEnv/OOPAOEnv.py:485-536.  Returns (obs, wfs_frame, reward, strehl, done, info)."""
+        a = self._action_tensor(action)
+        fr = self._frame
+        L.check(self._shard.lib.aoenv_step(
+            self._shard.h, int(i), C.c_void_p(a.data_ptr()), C.c_void_p(self._obs.data_ptr()),
+            C.c_void_p(fr.data_ptr()) if fr is not None else None, C.c_void_p(self._reward.data_ptr()),
+            C.c_void_p(self._strehl.data_ptr()), C.c_void_p(self._stream())))
+        strehl = self._strehl.clone()
+        self.SR.append(strehl)
+        if self.output == "numpy":
+            s = float(strehl[0])
+            return (self._out(self._obs), None if fr is None else self._out(fr), float(self._reward[0]), s, False,
+                    {"strehl": s})
+        done = _torch().zeros(self.n_envs, dtype=_torch().bool, device=self.device)
+        return self._obs.clone(), (None if fr is None else fr.clone()), self._reward.clone(), strehl, done, {"strehl": strehl}
+
+    def run_integrator(self, i0: int, n_steps: int, gain=None):
+        """On-device closed loop of MAIN/integrator_oopao_razor.py:66-91: ``action = gainCL * obs`` fused into
+        the step epilogue; returns the last (obs, reward, strehl).  ``reset_soft()`` (or a previous step) must
+        have produced the current observation."""
+        g = float(self.gainCL if gain is None else gain)
+        L.check(self._shard.lib.aoenv_run_integrator(
+            self._shard.h, int(i0), int(n_steps), g, C.c_void_p(self._obs.data_ptr()), None,
+            C.c_void_p(self._reward.data_ptr()), C.c_void_p(self._strehl.data_ptr()), C.c_void_p(self._stream())))
+        return self._obs, self._reward, self._strehl
+
+    def calculate_strehl_AVG(self):
+        """MAIN/OOPAOEnv/OOPAOEnv.py:538-546: (mean, std) over the episode, then clears the list."""
+        torch = _torch()
+        sr = torch.stack(self.SR) if len(self.SR) else torch.zeros((1, self.n_envs), device=self.device)
+        avg, std = sr.mean(dim=0), sr.std(dim=0, unbiased=False)
+        self.SR = []
+        if self.n_envs == 1:
+            return float(avg[0]), float(std[0])
+        return avg, std
+
+    def get_strehl(self):
+        return float(self._strehl[0]) if self.n_envs == 1 else self._strehl.clone()
+
+    def get_slopes(self):
+        return self.wfs.signal
+
+    @property
+    def total(self):
+        t = self._shard.download(L.B_TOTAL, (int(self.param.nLoop), self.n_envs), self._stream())
+        return t[:, 0] if self.n_envs == 1 else t
+
+    @property
+    def residual(self):
+        t = self._shard.download(L.B_RESIDUAL, (int(self.param.nLoop), self.n_envs), self._stream())
+        return t[:, 0] if self.n_envs == 1 else t
+
+    def sample_noise(self, sigma, use_torch=False):
+        """Exploration noise F @ (sigma N(0,1)^A) as an actuator image (MAIN/OOPAOEnv/OOPAOEnv.py:566-570)."""
+        torch = _torch()
+        if self.n_envs == 1:
+            noise = self.F @ (sigma * np.random.normal(0, 1, size=(int(self.nValidAct),)))
+            return self.vec_to_img(torch.tensor(noise).float().to(self.device), use_torch)
+        z = sigma * torch.randn((self.n_envs, self.nValidAct), device=self.device, dtype=self.tdtype)
+        return self.vec_to_img(z @ self._F_t.T, True)
+
+    def vec_to_img(self, action_vec, use_torch=False):
+        """MAIN/OOPAOEnv/OOPAOEnv.py:572-581, plus a leading batch dimension."""
+        torch = _torch()
+        if torch.is_tensor(action_vec) or use_torch:
+            v = torch.as_tensor(action_vec)
+            img = torch.zeros(v.shape[:-1] + (self.nActuator, self.nActuator), dtype=v.dtype if v.is_floating_point() else torch.float32,
+                              device=v.device)
+            img[..., self._xv_t.to(v.device), self._yv_t.to(v.device)] = v.to(img.dtype)
+            return img.float() if use_torch and v.dim() == 1 else img
+        v = np.asarray(action_vec)
+        img = np.zeros(v.shape[:-1] + (self.nActuator, self.nActuator))
+        img[..., self.xvalid, self.yvalid] = v
+        return img
+
+    def img_to_vec(self, action):
+        """MAIN/OOPAOEnv/OOPAOEnv.py:583-590 (2-D, batched 3-D and the 4-D network layout)."""
+        if _torch().is_tensor(action):
+            return action[..., self._xv_t.to(action.device), self._yv_t.to(action.device)]
+        return np.asarray(action)[..., self.xvalid, self.yvalid]
+
+    def close(self):
+        if self._shard is not None:
+            self._shard.close()
+            self._shard = None
+
+
+class OOPAO(BatchedAOEnv):
+    """Name-compatible single-env flavour: ``from rlao_amd.env import OOPAO`` in place of
+    ``from OOPAOEnv.OOPAOEnv import OOPAO`` (MAIN/PO4AO/mbrl.py:15) -- NumPy/float returns for the stock wrappers."""
+
+    def __init__(self, **kw):
+        kw.setdefault("n_envs", 1)
+        kw.setdefault("output", "numpy")
+        super().__init__(**kw)
+
+
+def namespace_from_yaml(path: str) -> SimpleNamespace:
+    """read_yaml_file + SimpleNamespace of MAIN/ML_stuff/dataset_tools.py:73 (safe loader)."""
+    import yaml
+    with open(path) as f:
+        return SimpleNamespace(**yaml.safe_load(f))

@@ -1,0 +1,96 @@
+"""CPU: the product's host-side constant tables (rlao_amd/calib.py) against the reference goldens.
+
+These tables are what the HIP kernels consume; they are pinned here directly against vectors the
+reference produced, independently of the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from rlao_amd import calib
+
+CASES = ["tiny_sh", "tiny_3layer", "small_sh", "c2_sh"]
+
+
+def params_of(g):
+    return calib.params_from_args(dict(
+        diameter=float(g["cfg_D"]), nSubaperture=int(g["cfg_nsub"]), nPixelPerSubap=int(g["cfg_R"]) // int(g["cfg_nsub"]),
+        r0=float(g["cfg_r0"]), L0=float(g["cfg_L0"]), windSpeed=list(g["cfg_ws"]), windDirection=list(g["cfg_wd"]),
+        fractionnalR0=list(g["cfg_frac"]), altitude=list(g["cfg_alt"]), nModes=int(g["cfg_n_modes"])))
+
+
+@pytest.fixture(scope="module", params=CASES)
+def case(request, golden_dir):
+    g = np.load(os.path.join(golden_dir, request.param + ".npz"))
+    return g, params_of(g)
+
+
+def test_telescope_source(case):
+    g, p = case
+    assert p.resolution == int(g["cfg_R"])
+    assert np.array_equal(calib.telescope_pupil(p.resolution, 0.0), g["pupil"])
+    wl, nph = calib.source(p.opticalBand, p.magnitude)
+    assert wl == float(g["wavelength"]) and nph == float(g["nPhoton"])
+
+
+def test_atmosphere_tables(case):
+    g, p = case
+    t = calib.AtmosphereTables(p)
+    assert t.n_inner == 8 * t.N - 16 and t.n_outer == 4 * t.N + 4
+    if "A" in g:
+        np.testing.assert_allclose(t.A, g["A"], atol=1e-12)
+        np.testing.assert_allclose(t.B, g["B"], atol=1e-12)
+    else:
+        np.testing.assert_allclose(t.A @ g["A_probe_in"], g["A_probe_out"], atol=1e-10)
+        np.testing.assert_allclose(t.B @ g["B_probe_in"], g["B_probe_out"], atol=1e-10)
+    # ring index tables reproduce the reference's boolean-mask scatter on its first screen
+    seed = int(g["cfg_seeds"][0])
+    m0 = g[f"s{seed}_mapShift0"][0]
+    Z = m0.reshape(-1)[t.inner_idx]
+    interior = m0[1:-1, 1:-1]
+    assert np.array_equal(Z, interior[t.inner_mask[1:-1, 1:-1]])
+    # the buff trajectory of the reference follows from wind_ratio alone
+    ratio = t.wind_ratio(p.windSpeed, p.windDirection, p.samplingTime)
+    buff = np.zeros_like(ratio)
+    for i in range(len(g[f"s{seed}_buff"])):
+        buff = buff + (np.abs(ratio) % 1) * np.sign(ratio)
+        buff = (np.abs(buff) % 1) * np.sign(buff)
+        np.testing.assert_allclose(buff, g[f"s{seed}_buff"][i], atol=1e-13)
+
+
+def test_new_phase_screen(case):
+    g, p = case
+    t = calib.AtmosphereTables(p)
+    seed = int(g["cfg_seeds"][0])
+    for l in range(p.nLayer):
+        scr = calib.new_phase_screen(p.r0, p.L0, t.N, t.layer_D / t.N, seed + l)
+        np.testing.assert_allclose(scr, g[f"s{seed}_mapShift0"][l][1:-1, 1:-1], atol=1e-11)
+
+
+def test_dm_tables(case):
+    g, p = case
+    dm = calib.DMTables(p)
+    assert np.array_equal(dm.validAct, g["validAct"])
+    assert np.array_equal(dm.xvalid, g["xvalid"]) and np.array_equal(dm.yvalid, g["yvalid"])
+    dense = dm.dense_modes()
+    if "modes" in g:
+        np.testing.assert_allclose(dense, g["modes"], atol=1e-15)
+    else:
+        np.testing.assert_allclose(dense @ g["modes_probe_in"], g["modes_probe_out"], atol=1e-12)
+    R = p.resolution
+    sep = np.einsum("yi,xj->yxij", dm.gy, dm.gx).reshape(R * R, -1)[:, dm.validAct]
+    np.testing.assert_allclose(sep, dense, atol=5e-16)
+
+
+def test_sh_tables_and_recon(case):
+    g, p = case
+    pupil = calib.telescope_pupil(p.resolution)
+    _, nph = calib.source(p.opticalBand, p.magnitude)
+    sh = calib.SHTables(p, pupil, nph)
+    assert np.array_equal(sh.valid_2d, g["valid_subap"])
+    recon, F = calib.reconstructor_from_imat(g["imat"], g["m2c"])
+    np.testing.assert_allclose(recon, g["recon"], atol=1e-9 * np.abs(g["recon"]).max())
+    if "F" in g:
+        np.testing.assert_allclose(F, g["F"], atol=1e-12)
+    if p.resolution != 120:
+        np.testing.assert_allclose(calib.zernike_m2c(calib.DMTables(p), pupil, p.diameter, p.nModes), g["m2c"], atol=1e-9)
