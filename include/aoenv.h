@@ -174,6 +174,17 @@ int aoenv_upload_state(AoEnv* env, int which, const void* h_src, size_t bytes, v
 int aoenv_get_buff(AoEnv* env, double* h_buff);
 int aoenv_set_buff(AoEnv* env, const double* h_buff);
 
+/* Per-kernel timing (bench.py roofline leg).  While enabled, every kernel launch of aoenv_step /
+ * aoenv_measure is bracketed by a hipEvent pair recorded on the launch stream; aoenv_profile_read
+ * synchronises the stream and returns the summed elapsed milliseconds and the launch count of each
+ * AoKernel.  aoenv_profile(env, 0|1) also clears the recorded events. */
+enum AoKernel {
+    AOENV_K_SHIFT_GATHER = 0, AOENV_K_MT_NORMAL, AOENV_K_GEMM_RING, AOENV_K_SCATTER, AOENV_K_PHASE,
+    AOENV_K_SH_SPOTS, AOENV_K_SH_CENTROID, AOENV_K_GEMM_RECON, AOENV_K_RECON_FINISH, AOENV_K_COUNT
+};
+int aoenv_profile(AoEnv* env, int enable);
+int aoenv_profile_read(AoEnv* env, double* h_ms, int32_t* h_count, void* stream);
+
 /* Test hook: draw `n` (even) values of RandomState(seed).normal(size=n) with the device MT19937 +
  * legacy polar generator into h_out (float64), to pin the stream against NumPy. */
 int aoenv_test_normal(int device, uint32_t seed, int n, int n_calls, double* h_out);

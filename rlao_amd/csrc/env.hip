@@ -75,6 +75,10 @@ struct AoEnv {
     void* vbuf = nullptr;                   // [E][A]
     void* obs_scratch = nullptr;            // [E][nAct*nAct]
     std::vector<void*> allocs;
+    // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
+    bool prof_on = false;
+    struct ProfEv { int stage; hipEvent_t a, b; };
+    std::vector<ProfEv> prof_ev;
 
     template <typename T> T* as(void* p_) const { return static_cast<T*>(p_); }
     void* screen_ptr(int which, int l) const {
@@ -92,6 +96,23 @@ int dmalloc(AoEnv* env, void** p, size_t bytes, bool zero = true) {
     if (zero) AO_HIP(hipMemset(*p, 0, bytes));
     return 0;
 }
+
+// Wraps one kernel launch in a hipEvent pair when profiling is enabled (events are recorded on the same
+// stream as the kernel, so the elapsed time is that kernel's device time plus its launch gap).
+struct ProfScope {
+    AoEnv* env; hipStream_t st; hipEvent_t a = nullptr, b = nullptr; int stage;
+    ProfScope(AoEnv* e, int stage_, hipStream_t s) : env(e), st(s), stage(stage_) {
+        if (!env->prof_on) return;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+        (void)hipEventRecord(a, st);
+    }
+    ~ProfScope() {
+        if (!a) return;
+        (void)hipEventRecord(b, st);
+        env->prof_ev.push_back({stage, a, b});
+    }
+};
+#define AO_PROF(env, stage, st) ProfScope prof_scope_##stage(env, AOENV_K_##stage, st)
 
 template <typename T>
 int upload_f64(void* dst, const double* src, size_t n) {
@@ -142,14 +163,26 @@ int extrude(AoEnv* env, int l, int sx, int sy, bool copy, hipStream_t st) {
     T* oldm = env->as<T>(env->screen_ptr(from, l));
     T* newm = env->as<T>(env->screen_ptr(to, l));
     T* zx = env->as<T>(env->zx);
-    AO_TRY(launch_shift_gather<T>(oldm, newm, zx, env->inner_idx, env->E, env->S, env->nin, env->K, sx, sy, copy ? 1 : 0,
-                                  st));
-    AO_TRY(launch_mt_normal<T>(env->mt_state + (size_t)l * env->E * kMtN, env->mt_pos + (size_t)l * env->E, zx, env->E,
-                               env->K, env->nin, env->nout, st));
-    AO_TRY(launch_gemm_nt<T>(zx, env->as<T>(env->ab), env->as<T>(env->xbuf), env->E, env->nout, env->K, env->K, env->K,
-                             env->nout, st));
-    AO_TRY(launch_scatter_minmax<T>(newm, env->as<T>(env->xbuf), env->outer_idx, env->as<T>(env->minmax_ptr(l)), env->E,
-                                    env->S, env->nout, st));
+    {
+        AO_PROF(env, SHIFT_GATHER, st);
+        AO_TRY(launch_shift_gather<T>(oldm, newm, zx, env->inner_idx, env->E, env->S, env->nin, env->K, sx, sy,
+                                      copy ? 1 : 0, st));
+    }
+    {
+        AO_PROF(env, MT_NORMAL, st);
+        AO_TRY(launch_mt_normal<T>(env->mt_state + (size_t)l * env->E * kMtN, env->mt_pos + (size_t)l * env->E, zx,
+                                   env->E, env->K, env->nin, env->nout, st));
+    }
+    {
+        AO_PROF(env, GEMM_RING, st);
+        AO_TRY(launch_gemm_nt<T>(zx, env->as<T>(env->ab), env->as<T>(env->xbuf), env->E, env->nout, env->K, env->K,
+                                 env->K, env->nout, st));
+    }
+    {
+        AO_PROF(env, SCATTER, st);
+        AO_TRY(launch_scatter_minmax<T>(newm, env->as<T>(env->xbuf), env->outer_idx, env->as<T>(env->minmax_ptr(l)),
+                                        env->E, env->S, env->nout, st));
+    }
     env->cur[l] = to;
     return 0;
 }
@@ -210,6 +243,7 @@ int run_phase(AoEnv* env, int update_atm, int telemetry_index, hipStream_t st) {
     pb.total = env->as<T>(env->total);
     pb.residual = env->as<T>(env->residual);
     pb.wfs_max = env->as<T>(env->wfs_max);
+    AO_PROF(env, PHASE, st);
     return launch_phase<T>(pa, pb, env->E, env->R, env->nAct, env->A, env->n_pupil, env->c.atm_wavelength,
                            env->c.src_wavelength, st);
 }
@@ -218,10 +252,16 @@ template <typename T>
 int run_wfs(AoEnv* env, hipStream_t st) {
     if (env->c.wfs_type != AOENV_WFS_SH) return fail("wfs_type %d is not implemented in this build", env->c.wfs_type);
     const ShConst<T> sc = sh_const<T>(env);
-    AO_TRY(launch_sh_spots<T>(env->as<T>(env->phase), sc, env->as<T>(env->frame), env->as<T>(env->wfs_max), env->E,
-                              env->R, env->nSub, env->nVal, st));
-    AO_TRY(launch_sh_centroid<T>(env->as<T>(env->frame), env->as<T>(env->wfs_max), sc, env->as<T>(env->signal), env->E,
-                                 env->R, env->nSub, env->nVal, env->c.max_group, st));
+    {
+        AO_PROF(env, SH_SPOTS, st);
+        AO_TRY(launch_sh_spots<T>(env->as<T>(env->phase), sc, env->as<T>(env->frame), env->as<T>(env->wfs_max), env->E,
+                                  env->R, env->nSub, env->nVal, st));
+    }
+    {
+        AO_PROF(env, SH_CENTROID, st);
+        AO_TRY(launch_sh_centroid<T>(env->as<T>(env->frame), env->as<T>(env->wfs_max), sc, env->as<T>(env->signal),
+                                     env->E, env->R, env->nSub, env->nVal, env->c.max_group, st));
+    }
     return 0;
 }
 
@@ -234,10 +274,16 @@ int refresh_dense_dm(AoEnv* env, hipStream_t st) {
 
 template <typename T>
 int run_recon(AoEnv* env, const T* d_action, T* d_obs, T* d_reward, int integrate, double gain, hipStream_t st) {
-    AO_TRY(launch_gemm_nt<T>(env->as<T>(env->signal), env->as<T>(env->recon), env->as<T>(env->vbuf), env->E, env->A,
-                             env->nSig, env->nSig, env->nSig, env->A, st));
-    AO_TRY(launch_recon_finish<T>(env->as<T>(env->vbuf), env->act_idx, d_action, env->as<T>(env->coefs), d_obs, d_reward,
-                                  env->E, env->nAct, env->A, env->c.leak, integrate, gain, st));
+    {
+        AO_PROF(env, GEMM_RECON, st);
+        AO_TRY(launch_gemm_nt<T>(env->as<T>(env->signal), env->as<T>(env->recon), env->as<T>(env->vbuf), env->E, env->A,
+                                 env->nSig, env->nSig, env->nSig, env->A, st));
+    }
+    {
+        AO_PROF(env, RECON_FINISH, st);
+        AO_TRY(launch_recon_finish<T>(env->as<T>(env->vbuf), env->act_idx, d_action, env->as<T>(env->coefs), d_obs,
+                                      d_reward, env->E, env->nAct, env->A, env->c.leak, integrate, gain, st));
+    }
     if (integrate) AO_TRY(refresh_dense_dm<T>(env, st));
     return 0;
 }
@@ -384,8 +430,9 @@ int aoenv_create(const AoCfg* cfg, int device, AoEnv** out) {
 
 int aoenv_destroy(AoEnv* env) {
     if (!env) return 0;
-    hipSetDevice(env->device);
-    for (void* p : env->allocs) hipFree(p);
+    (void)hipSetDevice(env->device);
+    for (auto& e : env->prof_ev) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (void* p : env->allocs) (void)hipFree(p);
     delete env;
     return 0;
 }
@@ -658,6 +705,28 @@ int aoenv_set_buff(AoEnv* env, const double* h_buff) {
     return 0;
 }
 
+int aoenv_profile(AoEnv* env, int enable) {
+    AO_CHECK_ENV(env);
+    for (auto& e : env->prof_ev) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    env->prof_ev.clear();
+    env->prof_on = enable != 0;
+    return 0;
+}
+
+int aoenv_profile_read(AoEnv* env, double* h_ms, int32_t* h_count, void* stream) {
+    AO_CHECK_ENV(env);
+    if (!h_ms || !h_count) return fail("null argument");
+    AO_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    for (int k = 0; k < AOENV_K_COUNT; ++k) { h_ms[k] = 0; h_count[k] = 0; }
+    for (auto& e : env->prof_ev) {
+        float ms = 0;
+        AO_HIP(hipEventElapsedTime(&ms, e.a, e.b));
+        h_ms[e.stage] += ms;
+        h_count[e.stage] += 1;
+    }
+    return 0;
+}
+
 int aoenv_test_normal(int device, uint32_t seed, int n, int n_calls, double* h_out) {
     if (n < 2 || n % 2 || n_calls < 1 || !h_out) return fail("aoenv_test_normal: bad arguments");
     AO_HIP(hipSetDevice(device));
@@ -675,7 +744,7 @@ int aoenv_test_normal(int device, uint32_t seed, int n, int n_calls, double* h_o
         rc = launch_mt_normal<double>(st, pos, zx, 1, n, 0, n, nullptr);
         if (!rc && hipMemcpy(h_out + (size_t)c * n, zx, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = fail("copy back failed");
     }
-    hipFree(st); hipFree(pos); hipFree(zx);
+    (void)hipFree(st); (void)hipFree(pos); (void)hipFree(zx);
     return rc;
 }
 

@@ -84,6 +84,18 @@ class Shard:
         a = np.ascontiguousarray(arr, dtype=self.np_dtype)
         L.check(self.lib.aoenv_upload_state(self.h, which, a.ctypes.data_as(C.c_void_p), a.nbytes, C.c_void_p(stream)))
 
+    def profile(self, enable: bool):
+        L.check(self.lib.aoenv_profile(self.h, int(enable)))
+
+    def profile_read(self, stream=0) -> dict:
+        """{kernel name: (total_ms, launches)} recorded since profile(True)."""
+        n = len(L.KERNEL_NAMES)
+        ms = np.zeros(n)
+        cnt = np.zeros(n, dtype=np.int32)
+        L.check(self.lib.aoenv_profile_read(self.h, ms.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p),
+                                            C.c_void_p(stream)))
+        return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(L.KERNEL_NAMES)}
+
     def get_buff(self, n_layer: int) -> np.ndarray:
         out = np.zeros((max(n_layer, 1), 2))
         L.check(self.lib.aoenv_get_buff(self.h, out.ctypes.data_as(C.c_void_p)))
