@@ -110,7 +110,9 @@ def main():
 
     if world > 1:                                   # warm the communicator outside the timed region
         aodist.all_gather_returns(returns, n_total)
-    env.run_integrator(0, W)
+    _, rew, _ = env.run_integrator(0, W)
+    returns += 0 * rew                              # first use of a torch kernel loads its code object: keep it out
+    float(returns.sum())                            # of the timed region
     barrier()
     t0 = time.perf_counter()
     for k in range(K):

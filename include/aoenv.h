@@ -174,6 +174,13 @@ int aoenv_upload_state(AoEnv* env, int which, const void* h_src, size_t bytes, v
 int aoenv_get_buff(AoEnv* env, double* h_buff);
 int aoenv_set_buff(AoEnv* env, const double* h_buff);
 
+/* Implementation switches (parity tests compare the specialised kernels with the generic ones). */
+enum AoOption {
+    AOENV_OPT_FAST_WFS = 0,  /* 1 (default): register-resident 6 px/lenslet SH kernel; 0: generic LDS kernel */
+    AOENV_OPT_MFMA_GEMM = 1  /* 1 (default): float32 split-K MFMA contractions; 0: generic tiled VALU kernel */
+};
+int aoenv_set_option(AoEnv* env, int option, int value);
+
 /* Per-kernel timing (bench.py roofline leg).  While enabled, every kernel launch of aoenv_step /
  * aoenv_measure is bracketed by a hipEvent pair recorded on the launch stream; aoenv_profile_read
  * synchronises the stream and returns the summed elapsed milliseconds and the launch count of each

@@ -19,6 +19,7 @@ WFS_SH, WFS_PYRAMID = 0, 1
 (B_SCREEN, B_OPD_ATM, B_COEFS, B_PHASE, B_FRAME, B_SIGNAL, B_TOTAL, B_RESIDUAL, B_WFS_MAX, B_XI) = range(10)
 
 
+OPT_FAST_WFS, OPT_MFMA_GEMM = 0, 1
 KERNEL_NAMES = ("shift_gather", "mt_normal", "gemm_ring", "scatter_minmax", "phase", "sh_spots", "sh_centroid",
                 "gemm_recon", "recon_finish")
 
@@ -53,6 +54,7 @@ EXPORTS = {
     "aoenv_upload_state": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "aoenv_get_buff": (C.c_int, [C.c_void_p, C.c_void_p]),
     "aoenv_set_buff": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "aoenv_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "aoenv_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "aoenv_profile_read": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "aoenv_test_normal": (C.c_int, [C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_void_p]),

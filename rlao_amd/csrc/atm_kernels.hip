@@ -183,14 +183,15 @@ int launch_mt_normal(uint32_t* mt_state, int* mt_pos, T* zx, int n_env, int K, i
 template <typename T>
 __global__ void __launch_bounds__(1024) k_scatter_minmax(T* __restrict__ new_map, const T* __restrict__ X,
                                                          const int* __restrict__ outer_idx, T* __restrict__ minmax,
-                                                         int S, int n_outer) {
+                                                         int S, int n_outer, int splits, size_t slab) {
     __shared__ T red_lo[16], red_hi[16];
     const int e = blockIdx.x;
     T* map = new_map + (size_t)e * S * S;
     const T* x = X + (size_t)e * n_outer;
     T lo = (T)3.0e38, hi = (T)-3.0e38;
     for (int k = threadIdx.x; k < n_outer; k += blockDim.x) {
-        const T v = x[k];
+        T v = x[k];
+        for (int z = 1; z < splits; ++z) v += x[(size_t)z * slab + k];       // split-K slabs, fixed order
         map[outer_idx[k]] = v;
         lo = v < lo ? v : lo;
         hi = v > hi ? v : hi;
@@ -224,9 +225,9 @@ __global__ void __launch_bounds__(1024) k_scatter_minmax(T* __restrict__ new_map
 
 template <typename T>
 int launch_scatter_minmax(T* new_map, const T* X, const int* outer_idx, T* minmax, int n_env, int S, int n_outer,
-                          hipStream_t st) {
+                          int splits, hipStream_t st) {
     hipLaunchKernelGGL(k_scatter_minmax<T>, dim3(n_env), dim3(1024), 0, st, new_map, X, outer_idx, minmax, S,
-                       n_outer);
+                       n_outer, splits, (size_t)n_env * n_outer);
     AO_HIP(hipGetLastError());
     return 0;
 }
@@ -235,7 +236,7 @@ int launch_scatter_minmax(T* new_map, const T* X, const int* outer_idx, T* minma
     template int launch_shift_gather<T>(const T*, T*, T*, const int*, int, int, int, int, int, int, int,           \
                                         hipStream_t);                                                              \
     template int launch_mt_normal<T>(uint32_t*, int*, T*, int, int, int, int, hipStream_t);                        \
-    template int launch_scatter_minmax<T>(T*, const T*, const int*, T*, int, int, int, hipStream_t);
+    template int launch_scatter_minmax<T>(T*, const T*, const int*, T*, int, int, int, int, hipStream_t);
 INST(float)
 INST(double)
 #undef INST

@@ -14,6 +14,7 @@ namespace ao {
 constexpr int kWave = 64;          // CDNA wavefront
 constexpr int kMaxLayer = 8;
 constexpr int kMtN = 624;          // MT19937 state words
+constexpr int kMaxSplits = 16;     // split-K slabs of the float32 MFMA GEMM
 
 int fail(const char* fmt, ...);
 #define AO_HIP(call)                                                                          \
@@ -49,7 +50,6 @@ struct PhaseArgs {
     int S;                           // N + 2
     int foot;                        // offset of the R x R pupil footprint inside the (N+2)^2 screen
     int update_atm;                  // 1: recompute opd_atm from the screens; 0: keep the buffer
-    int telemetry_index;             // >= 0: write total[i], residual[i]
 };
 
 }  // namespace ao
@@ -67,7 +67,10 @@ int launch_mt_normal(uint32_t* mt_state, int* mt_pos, T* zx, int n_env, int K, i
                      hipStream_t st);
 template <typename T>
 int launch_scatter_minmax(T* new_map, const T* X, const int* outer_idx, T* minmax, int n_env, int S, int n_outer,
-                          hipStream_t st);
+                          int splits, hipStream_t st);
+int gemm_splits(int M, int N, int K);
+int launch_gemm_nt_mfma(const float* X, const float* W, float* Cpart, int M, int N, int K, int ldx, int ldw, int splits,
+                        hipStream_t st);
 template <typename T>
 int launch_gemm_nt(const T* X, const T* W, T* C, int M, int N, int K, int ldx, int ldw, int ldc, hipStream_t st);
 
@@ -81,19 +84,19 @@ struct PhaseBuffers {
     const int* act_idx;    // [A]
     const uint8_t* pupil;  // [R*R]
     T* phase;              // [E][R*R]
-    T* scal;               // [E][4]: total_nm, residual_nm, strehl, (unused)
-    T* total;              // [n_loop][E]
-    T* residual;           // [n_loop][E]
+    double* part;          // [E][tiles][4] per-tile Sum / Sum^2 of the atmosphere and residual OPD over the pupil
     T* wfs_max;            // [E] zeroed here for the WFS kernels
 };
+int phase_tiles(int R);
 template <typename T>
 int launch_phase(const PhaseArgs& pa, const PhaseBuffers<T>& pb, int n_env, int R, int n_act, int n_valid_act,
-                 int n_pupil, double atm_wavelength, double src_wavelength, hipStream_t st);
+                 double atm_wavelength, double src_wavelength, hipStream_t st);
 
 template <typename T>
 struct ShConst {
     const T* amp;            // [R*R]
     const int* subap_idx;    // [nValid]
+    const uint8_t* valid2d;  // [n_subap^2] 1 = valid lenslet (fast P = 6 path), may be null
     const T* ref;            // [2*nValid]
     const T* tw;             // [n][2]   exp(-2 pi i k / n)
     const T* ph;             // [p][2]   phasor at padded coordinate a + lo
@@ -107,12 +110,28 @@ template <typename T>
 int launch_sh_centroid(const T* frame, const T* wfs_max, const ShConst<T>& sc, T* signal, int n_env, int R,
                        int n_subap, int n_valid, int max_group, hipStream_t st);
 
+// Step epilogue (one workgroup per env): reconstruction image, reward, integrator, telemetry scalars.
 template <typename T>
-int launch_recon_finish(const T* v, const int* act_idx, const T* action, T* coefs, T* obs, T* reward, int n_env,
-                        int n_act, int n_valid_act, double leak, int do_integrate, double gain_from_obs,
-                        hipStream_t st);
+struct FinishArgs {
+    const T* v;              // [splits][E][A] split-K slabs of R.s
+    int splits;
+    const int* act_idx;      // [A]
+    const T* action;         // [E][nAct^2] or null (gain_from_obs != 0)
+    T* coefs;                // [E][A]
+    T* obs;                  // [E][nAct^2]
+    T* reward;               // [E] or null
+    T* strehl;               // [E] or null
+    T* scal;                 // [E][4] total_nm, residual_nm, strehl
+    T* total;                // [n_loop][E]
+    T* residual;             // [n_loop][E]
+    const double* part;      // [E][tiles][4]
+    int n_tiles, n_pupil, telemetry_index;
+    int n_act, n_valid_act, do_integrate;
+    T leak, gain_from_obs;
+    double src_scale;        // 2 pi / lambda_src
+};
 template <typename T>
-int launch_copy_scal(const T* scal, T* d_strehl, int n_env, hipStream_t st);
+int launch_recon_finish(const FinishArgs<T>& fa, int n_env, hipStream_t st);
 template <typename T>
 int launch_convert_from_f64(const double* src, T* dst, size_t n, hipStream_t st);
 

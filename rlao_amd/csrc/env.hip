@@ -61,11 +61,14 @@ struct AoEnv {
     void* coefs = nullptr;
     void* phase = nullptr;
     void* scal = nullptr;                   // [E][4]
+    double* part = nullptr;                 // [E][tiles][4] telemetry partial sums of the phase kernel
+    int n_tiles = 0;
     void* total = nullptr;
     void* residual = nullptr;
     void* wfs_max = nullptr;
     void* amp = nullptr;
     int* subap_idx = nullptr;
+    uint8_t* valid2d = nullptr;             // [nSub*nSub]
     void* sh_ref = nullptr;
     void* tw = nullptr;
     void* phs = nullptr;
@@ -76,6 +79,8 @@ struct AoEnv {
     void* obs_scratch = nullptr;            // [E][nAct*nAct]
     std::vector<void*> allocs;
     // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
+    bool use_fast_wfs = true;               // aoenv_set_option(AOENV_OPT_FAST_WFS)
+    bool use_mfma = true;                   // aoenv_set_option(AOENV_OPT_MFMA_GEMM)
     bool prof_on = false;
     struct ProfEv { int stage; hipEvent_t a, b; };
     std::vector<ProfEv> prof_ev;
@@ -148,12 +153,30 @@ ShConst<T> sh_const(const AoEnv* env) {
     ShConst<T> sc;
     sc.amp = env->as<T>(env->amp);
     sc.subap_idx = env->subap_idx;
+    sc.valid2d = env->use_fast_wfs ? env->valid2d : nullptr;
     sc.ref = env->as<T>(env->sh_ref);
     sc.tw = env->as<T>(env->tw);
     sc.ph = env->as<T>(env->phs);
     sc.units = (T)env->units;
     sc.threshold = (T)env->c.threshold_cog;
     return sc;
+}
+
+// C[M][N] (+ split-K slabs) = X . W^T: float32 shards use the MFMA kernel, float64 the generic one.
+template <typename T>
+int gemm_dispatch(AoEnv* env, const T* X, const T* W, T* C, int M, int N, int K, int* splits, hipStream_t st);
+template <>
+int gemm_dispatch<float>(AoEnv* env, const float* X, const float* W, float* C, int M, int N, int K, int* splits,
+                         hipStream_t st) {
+    if (!env->use_mfma) { *splits = 1; return launch_gemm_nt<float>(X, W, C, M, N, K, K, K, N, st); }
+    *splits = gemm_splits(M, N, K);
+    return launch_gemm_nt_mfma(X, W, C, M, N, K, K, K, *splits, st);
+}
+template <>
+int gemm_dispatch<double>(AoEnv*, const double* X, const double* W, double* C, int M, int N, int K, int* splits,
+                          hipStream_t st) {
+    *splits = 1;
+    return launch_gemm_nt<double>(X, W, C, M, N, K, K, K, N, st);
 }
 
 // ---- add_row on the device (OOPAO/Atmosphere.py:301-311) for every env of the shard ---------------
@@ -173,15 +196,16 @@ int extrude(AoEnv* env, int l, int sx, int sy, bool copy, hipStream_t st) {
         AO_TRY(launch_mt_normal<T>(env->mt_state + (size_t)l * env->E * kMtN, env->mt_pos + (size_t)l * env->E, zx,
                                    env->E, env->K, env->nin, env->nout, st));
     }
+    int splits = 1;
     {
         AO_PROF(env, GEMM_RING, st);
-        AO_TRY(launch_gemm_nt<T>(zx, env->as<T>(env->ab), env->as<T>(env->xbuf), env->E, env->nout, env->K, env->K,
-                                 env->K, env->nout, st));
+        AO_TRY(gemm_dispatch<T>(env, zx, env->as<T>(env->ab), env->as<T>(env->xbuf), env->E, env->nout, env->K, &splits,
+                                st));
     }
     {
         AO_PROF(env, SCATTER, st);
         AO_TRY(launch_scatter_minmax<T>(newm, env->as<T>(env->xbuf), env->outer_idx, env->as<T>(env->minmax_ptr(l)),
-                                        env->E, env->S, env->nout, st));
+                                        env->E, env->S, env->nout, splits, st));
     }
     env->cur[l] = to;
     return 0;
@@ -211,13 +235,12 @@ int advance_atmosphere(AoEnv* env, hipStream_t st) {
 }
 
 template <typename T>
-int run_phase(AoEnv* env, int update_atm, int telemetry_index, hipStream_t st) {
+int run_phase(AoEnv* env, int update_atm, hipStream_t st) {
     PhaseArgs pa{};
     pa.n_layer = env->L;
     pa.S = env->S;
     pa.foot = (env->N / 2 - env->R / 2) + 1;
     pa.update_atm = (update_atm && env->L > 0) ? 1 : 0;
-    pa.telemetry_index = telemetry_index;
     for (int l = 0; l < env->L; ++l) {
         pa.screen[l] = env->screen_ptr(env->cur[l], l);
         pa.minmax[l] = env->minmax_ptr(l);
@@ -239,13 +262,11 @@ int run_phase(AoEnv* env, int update_atm, int telemetry_index, hipStream_t st) {
     pb.act_idx = env->act_idx;
     pb.pupil = env->pupil;
     pb.phase = env->as<T>(env->phase);
-    pb.scal = env->as<T>(env->scal);
-    pb.total = env->as<T>(env->total);
-    pb.residual = env->as<T>(env->residual);
+    pb.part = env->part;
     pb.wfs_max = env->as<T>(env->wfs_max);
     AO_PROF(env, PHASE, st);
-    return launch_phase<T>(pa, pb, env->E, env->R, env->nAct, env->A, env->n_pupil, env->c.atm_wavelength,
-                           env->c.src_wavelength, st);
+    return launch_phase<T>(pa, pb, env->E, env->R, env->nAct, env->A, env->c.atm_wavelength, env->c.src_wavelength,
+                           st);
 }
 
 template <typename T>
@@ -273,16 +294,39 @@ int refresh_dense_dm(AoEnv* env, hipStream_t st) {
 }
 
 template <typename T>
-int run_recon(AoEnv* env, const T* d_action, T* d_obs, T* d_reward, int integrate, double gain, hipStream_t st) {
+int run_recon(AoEnv* env, const T* d_action, T* d_obs, T* d_reward, T* d_strehl, int telemetry_index, int integrate,
+              double gain, hipStream_t st) {
+    int splits = 1;
     {
         AO_PROF(env, GEMM_RECON, st);
-        AO_TRY(launch_gemm_nt<T>(env->as<T>(env->signal), env->as<T>(env->recon), env->as<T>(env->vbuf), env->E, env->A,
-                                 env->nSig, env->nSig, env->nSig, env->A, st));
+        AO_TRY(gemm_dispatch<T>(env, env->as<T>(env->signal), env->as<T>(env->recon), env->as<T>(env->vbuf), env->E,
+                                env->A, env->nSig, &splits, st));
     }
     {
+        FinishArgs<T> fa{};
+        fa.v = env->as<T>(env->vbuf);
+        fa.splits = splits;
+        fa.act_idx = env->act_idx;
+        fa.action = d_action;
+        fa.coefs = env->as<T>(env->coefs);
+        fa.obs = d_obs;
+        fa.reward = d_reward;
+        fa.strehl = d_strehl;
+        fa.scal = env->as<T>(env->scal);
+        fa.total = env->as<T>(env->total);
+        fa.residual = env->as<T>(env->residual);
+        fa.part = env->part;
+        fa.n_tiles = env->n_tiles;
+        fa.n_pupil = env->n_pupil;
+        fa.telemetry_index = telemetry_index;
+        fa.n_act = env->nAct;
+        fa.n_valid_act = env->A;
+        fa.do_integrate = integrate;
+        fa.leak = (T)env->c.leak;
+        fa.gain_from_obs = (T)gain;
+        fa.src_scale = 6.283185307179586476925286766559 / env->c.src_wavelength;
         AO_PROF(env, RECON_FINISH, st);
-        AO_TRY(launch_recon_finish<T>(env->as<T>(env->vbuf), env->act_idx, d_action, env->as<T>(env->coefs), d_obs,
-                                      d_reward, env->E, env->nAct, env->A, env->c.leak, integrate, gain, st));
+        AO_TRY(launch_recon_finish<T>(fa, env->E, st));
     }
     if (integrate) AO_TRY(refresh_dense_dm<T>(env, st));
     return 0;
@@ -292,11 +336,10 @@ template <typename T>
 int step_t(AoEnv* env, int i, const void* d_action, void* d_obs, void* d_frame, void* d_reward, void* d_strehl,
            double gain, hipStream_t st) {
     AO_TRY(advance_atmosphere<T>(env, st));
-    AO_TRY(run_phase<T>(env, 1, i, st));
+    AO_TRY(run_phase<T>(env, 1, st));
     AO_TRY(run_wfs<T>(env, st));
-    AO_TRY(run_recon<T>(env, static_cast<const T*>(d_action), static_cast<T*>(d_obs), static_cast<T*>(d_reward), 1, gain,
-                        st));
-    if (d_strehl) AO_TRY(launch_copy_scal<T>(env->as<T>(env->scal), static_cast<T*>(d_strehl), env->E, st));
+    AO_TRY(run_recon<T>(env, static_cast<const T*>(d_action), static_cast<T*>(d_obs), static_cast<T*>(d_reward),
+                        static_cast<T*>(d_strehl), i, 1, gain, st));
     if (d_frame)
         AO_HIP(hipMemcpyAsync(d_frame, env->frame, (size_t)env->E * env->c.cam_res * env->c.cam_res * sizeof(T),
                               hipMemcpyDeviceToDevice, st));
@@ -377,7 +420,7 @@ int aoenv_create(const AoCfg* cfg, int device, AoEnv** out) {
         A_((void**)&e->mt_state, (size_t)e->L * E * kMtN * 4);
         A_((void**)&e->mt_pos, (size_t)e->L * E * 4);
         A_(&e->zx, E * e->K * z);
-        A_(&e->xbuf, E * e->nout * z);
+        A_(&e->xbuf, (size_t)kMaxSplits * E * e->nout * z);
         A_(&e->ab, (size_t)e->nout * e->K * z);
         A_((void**)&e->inner_idx, (size_t)e->nin * 4);
         A_((void**)&e->outer_idx, (size_t)e->nout * 4);
@@ -394,18 +437,21 @@ int aoenv_create(const AoCfg* cfg, int device, AoEnv** out) {
     A_(&e->coefs, E * e->A * z);
     A_(&e->phase, E * R2 * z);
     A_(&e->scal, E * 4 * z);
+    e->n_tiles = phase_tiles(e->R);
+    A_((void**)&e->part, E * (size_t)e->n_tiles * 4 * sizeof(double));
     A_(&e->total, (size_t)cfg->n_loop * E * z);
     A_(&e->residual, (size_t)cfg->n_loop * E * z);
     A_(&e->wfs_max, E * z);
     A_(&e->amp, R2 * z);
     A_((void**)&e->subap_idx, (size_t)e->nVal * 4);
+    A_((void**)&e->valid2d, (size_t)e->nSub * e->nSub);
     A_(&e->sh_ref, (size_t)2 * e->nVal * z);
     A_(&e->tw, (size_t)e->n * 2 * z);
     A_(&e->phs, (size_t)e->p * 2 * z);
     A_(&e->frame, E * (size_t)cfg->cam_res * cfg->cam_res * z);
     A_(&e->signal, E * e->nSig * z);
     A_(&e->recon, (size_t)e->A * e->nSig * z);
-    A_(&e->vbuf, E * e->A * z);
+    A_(&e->vbuf, (size_t)kMaxSplits * E * e->A * z);
     A_(&e->obs_scratch, E * (size_t)e->nAct * e->nAct * z);
     if (rc) { aoenv_destroy(e); return rc; }
 
@@ -505,6 +551,9 @@ int aoenv_upload(AoEnv* env, int kind, const void* h, size_t bytes) {
             for (int i = 0; i < env->nVal; ++i)
                 if (ix[i] < 0 || ix[i] >= env->nSub * env->nSub) return fail("lenslet index %d out of range", ix[i]);
             AO_HIP(hipMemcpy(env->subap_idx, h, (size_t)env->nVal * 4, hipMemcpyHostToDevice));
+            std::vector<uint8_t> v2((size_t)env->nSub * env->nSub, 0);
+            for (int i = 0; i < env->nVal; ++i) v2[ix[i]] = 1;
+            AO_HIP(hipMemcpy(env->valid2d, v2.data(), v2.size(), hipMemcpyHostToDevice));
             break;
         }
         case AOENV_C_SH_REF:
@@ -584,7 +633,7 @@ int aoenv_new_screens(AoEnv* env, const double* h_screens, const uint32_t* h_rin
         env->clk[l].buff[0] = env->clk[l].buff[1] = 0;            // notDoneOnce (OOPAO/Atmosphere.py:586, 359-364)
         AO_TRY(AO_DISPATCH(env, extrude, env, l, 0, 0, false, st));
     }
-    AO_TRY(AO_DISPATCH(env, run_phase, env, 1, -1, st));           // fill_phase_support + set_OPD + atm*tel
+    AO_TRY(AO_DISPATCH(env, run_phase, env, 1, st));               // fill_phase_support + set_OPD + atm*tel
     return 0;
 }
 
@@ -611,7 +660,7 @@ int aoenv_measure(AoEnv* env, void* stream) {
     AO_CHECK_ENV(env);
     AO_TRY(require_step_constants(env, false));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    AO_TRY(AO_DISPATCH(env, run_phase, env, 0, -1, st));
+    AO_TRY(AO_DISPATCH(env, run_phase, env, 0, st));
     return AO_DISPATCH(env, run_wfs, env, st);
 }
 
@@ -620,8 +669,9 @@ int aoenv_reset_soft(AoEnv* env, void* d_obs, void* stream) {
     if (!d_obs) return fail("null obs");
     if (!env->have[AOENV_C_RECON]) return fail("the reconstructor has not been uploaded");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (env->c.dtype == AOENV_F32) return run_recon<float>(env, nullptr, static_cast<float*>(d_obs), nullptr, 0, 0.0, st);
-    return run_recon<double>(env, nullptr, static_cast<double*>(d_obs), nullptr, 0, 0.0, st);
+    if (env->c.dtype == AOENV_F32)
+        return run_recon<float>(env, nullptr, static_cast<float*>(d_obs), nullptr, nullptr, -1, 0, 0.0, st);
+    return run_recon<double>(env, nullptr, static_cast<double*>(d_obs), nullptr, nullptr, -1, 0, 0.0, st);
 }
 
 int aoenv_step(AoEnv* env, int i, const void* d_action, void* d_obs, void* d_frame, void* d_reward, void* d_strehl,
@@ -703,6 +753,15 @@ int aoenv_set_buff(AoEnv* env, const double* h_buff) {
         env->clk[l].buff[0] = h_buff[2 * l]; env->clk[l].buff[1] = h_buff[2 * l + 1];
     }
     return 0;
+}
+
+int aoenv_set_option(AoEnv* env, int option, int value) {
+    AO_CHECK_ENV(env);
+    switch (option) {
+        case AOENV_OPT_FAST_WFS: env->use_fast_wfs = value != 0; return 0;
+        case AOENV_OPT_MFMA_GEMM: env->use_mfma = value != 0; return 0;
+        default: return fail("unknown option %d", option);
+    }
 }
 
 int aoenv_profile(AoEnv* env, int enable) {

@@ -68,6 +68,96 @@ int launch_gemm_nt(const T* X, const T* W, T* C, int M, int N, int K, int ldx, i
 }
 
 // ---------------------------------------------------------------------------------------------------
+// float32 MFMA path: v_mfma_f32_32x32x2_f32 (exact f32, k-ordered fma chain), split-K.
+// M = n_env is small (256) and W is shared by every env, so a plain 64 x 64 tiling leaves most CUs idle:
+// the K range is cut into `splits` slices (gridDim.z) and every slice writes its own partial slab
+// Cpart[z][M][N]; the consumer kernel adds the slabs in slice order, which keeps the result bitwise
+// reproducible (no float atomics).  Workgroup = 4 waves as 2 (M) x 2 (N), one 32 x 32 accumulator each.
+// LDS tiles are [64][BK + 1] floats: lane l of a wave reads row (l & 31), k = 2 kk + (l >> 5), i.e. the 32
+// rows of a half-wave fall in 32 different banks (row stride 33).
+// ---------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ void __launch_bounds__(256) k_gemm_nt_mfma(const float* __restrict__ X, const float* __restrict__ W,
+                                                      float* __restrict__ Cpart, int M, int N, int K, int ldx,
+                                                      int ldw, int kslice) {
+    constexpr int BM = 64, BN = 64, BK = 32, LDT = BK + 1;
+    __shared__ float xs[BM * LDT];
+    __shared__ float ws[BN * LDT];
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * kslice, kend = min(K, kbeg + kslice);
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const int lr = lane & 31, lh = lane >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const bool vec_ok = ((ldx | ldw) & 3) == 0;            // rows 16-byte aligned -> float4 staging loads
+
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        // stage 64 x 32 of X and of W: thread t -> row t/8 (+32), k offset (t%8)*4
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int r = (threadIdx.x >> 3) + pass * 32, kq = (threadIdx.x & 7) * 4;
+            const int gk = k0 + kq;
+            float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), wv = xv;
+            const int gm = m0 + r, gn = n0 + r;
+            if (vec_ok && gk + 3 < kend) {
+                if (gm < M) xv = *reinterpret_cast<const float4*>(X + (size_t)gm * ldx + gk);
+                if (gn < N) wv = *reinterpret_cast<const float4*>(W + (size_t)gn * ldw + gk);
+            } else {
+                float* xp = reinterpret_cast<float*>(&xv);
+                float* wp = reinterpret_cast<float*>(&wv);
+                for (int d = 0; d < 4; ++d) {
+                    if (gk + d < kend) {
+                        if (gm < M) xp[d] = X[(size_t)gm * ldx + gk + d];
+                        if (gn < N) wp[d] = W[(size_t)gn * ldw + gk + d];
+                    }
+                }
+            }
+            float* xd = xs + r * LDT + kq;
+            float* wd = ws + r * LDT + kq;
+            xd[0] = xv.x; xd[1] = xv.y; xd[2] = xv.z; xd[3] = xv.w;
+            wd[0] = wv.x; wd[1] = wv.y; wd[2] = wv.z; wd[3] = wv.w;
+        }
+        __syncthreads();
+        const float* xa = xs + (wm + lr) * LDT + lh;
+        const float* wb = ws + (wn + lr) * LDT + lh;
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[2 * kk], wb[2 * kk], acc, 0, 0, 0);
+        __syncthreads();
+    }
+    // C/D map of the 32x32 shape: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    float* C = Cpart + (size_t)blockIdx.z * M * N;
+    const int gn = n0 + wn + lr;
+    if (gn < N) {
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg) {
+            const int gm = m0 + wm + (rg & 3) + 8 * (rg >> 2) + 4 * lh;
+            if (gm < M) C[(size_t)gm * N + gn] = acc[rg];
+        }
+    }
+}
+
+int gemm_splits(int M, int N, int K) {
+    const int tiles = cdiv(M, 64) * cdiv(N, 64);
+    int s = cdiv(512, tiles);
+    const int smax = K / 64 > 0 ? K / 64 : 1;
+    s = s < 1 ? 1 : (s > smax ? smax : s);
+    return s > kMaxSplits ? kMaxSplits : s;
+}
+
+int launch_gemm_nt_mfma(const float* X, const float* W, float* Cpart, int M, int N, int K, int ldx, int ldw, int splits,
+                        hipStream_t st) {
+    const int kslice = cdiv(cdiv(K, splits), 32) * 32;
+    dim3 grid(cdiv(N, 64), cdiv(M, 64), splits);
+    hipLaunchKernelGGL(k_gemm_nt_mfma, grid, dim3(256), 0, st, X, W, Cpart, M, N, K, ldx, ldw, kslice);
+    AO_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Step epilogue, one workgroup per env   (MAIN/OOPAOEnv/OOPAOEnv.py:491, 508-518, 536):
 //   obs_img = vec_to_img(-v) * 1e6 ; reward = -||obs_img||_2
 //   dm.coefs = dm.coefs * leak + img_to_vec(action) * 1e-6          (do_integrate)
@@ -76,33 +166,33 @@ int launch_gemm_nt(const T* X, const T* W, T* C, int M, int N, int K, int ldx, i
 // image is consumed before it is overwritten.
 // ---------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void __launch_bounds__(256) k_recon_finish(const T* __restrict__ v, const int* __restrict__ act_idx,
-                                                      const T* __restrict__ action, T* __restrict__ coefs,
-                                                      T* __restrict__ obs, T* __restrict__ reward, int n_act,
-                                                      int n_valid_act, T leak, int do_integrate, T gain_from_obs) {
+__global__ void __launch_bounds__(256) k_recon_finish(const FinishArgs<T> f) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     T* img_s = reinterpret_cast<T*>(lds_raw);          // the full image, zero at non-actuators (vec_to_img)
     __shared__ double red[4];
-    const int e = blockIdx.x;
-    const int img = n_act * n_act;
-    T* ob = obs + (size_t)e * img;
-    const T* vv = v + (size_t)e * n_valid_act;
+    const int e = blockIdx.x, n_env = gridDim.x;
+    const int img = f.n_act * f.n_act;
+    T* ob = f.obs + (size_t)e * img;
+    const size_t slab = (size_t)n_env * f.n_valid_act;
+    const T* vv = f.v + (size_t)e * f.n_valid_act;
     for (int q = threadIdx.x; q < img; q += blockDim.x) img_s[q] = (T)0;
     __syncthreads();
     double ss = 0.0;
-    for (int k = threadIdx.x; k < n_valid_act; k += blockDim.x) {
-        const int px = act_idx[k];
-        if (do_integrate) {
-            const T a = (gain_from_obs != (T)0) ? gain_from_obs * ob[px] : action[(size_t)e * img + px];
-            T* c = coefs + (size_t)e * n_valid_act + k;
+    for (int k = threadIdx.x; k < f.n_valid_act; k += blockDim.x) {
+        const int px = f.act_idx[k];
+        if (f.do_integrate) {
+            const T a = (f.gain_from_obs != (T)0) ? f.gain_from_obs * ob[px] : f.action[(size_t)e * img + px];
+            T* c = f.coefs + (size_t)e * f.n_valid_act + k;
             // img_to_vec(action)*1e-6 (OOPAOEnv.py:491): the wrappers hand over float32 actions and NumPy keeps
             // float32 for array * python-float, so the increment is a float32 product; a float64 action that is
             // not float32-representable (env driven without the torch wrapper) keeps the float64 product.
             const float af = (float)a;
             const T inc = ((T)af == a) ? (T)(af * 1e-6f) : a * (T)1e-6;
-            *c = (*c) * leak + inc;
+            *c = (*c) * f.leak + inc;
         }
-        const T o = -vv[k] * (T)1e6;
+        T acc = vv[k];
+        for (int z = 1; z < f.splits; ++z) acc += vv[(size_t)z * slab + k];      // split-K slabs, fixed order
+        const T o = -acc * (T)1e6;
         img_s[px] = o;
         ss += (double)o * (double)o;
     }
@@ -111,27 +201,36 @@ __global__ void __launch_bounds__(256) k_recon_finish(const T* __restrict__ v, c
     for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off);
     if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x / kWave] = ss;
     __syncthreads();
-    if (threadIdx.x == 0 && reward) reward[e] = (T)(-sqrt(red[0] + red[1] + red[2] + red[3]));
+    if (threadIdx.x == 0) {
+        if (f.reward) f.reward[e] = (T)(-sqrt(red[0] + red[1] + red[2] + red[3]));
+        // telemetry from the phase kernel's per-tile sums (fixed order): std(OPD[pupil]) * 1e9, exp(-var(phase[pupil]))
+        double v[4] = {0, 0, 0, 0};
+        const double* pp = f.part + (size_t)e * f.n_tiles * 4;
+        for (int t = 0; t < f.n_tiles; ++t)
+            for (int k = 0; k < 4; ++k) v[k] += pp[t * 4 + k];
+        const double n = (double)f.n_pupil;
+        double var_atm = v[1] / n - (v[0] / n) * (v[0] / n);
+        double var_res = v[3] / n - (v[2] / n) * (v[2] / n);
+        var_atm = var_atm > 0 ? var_atm : 0;
+        var_res = var_res > 0 ? var_res : 0;
+        const double total = sqrt(var_atm) * 1e9, resid = sqrt(var_res) * 1e9;
+        const double sr = exp(-var_res * f.src_scale * f.src_scale);
+        T* sc = f.scal + 4 * e;
+        sc[0] = (T)total;
+        sc[1] = (T)resid;
+        sc[2] = (T)sr;
+        if (f.strehl) f.strehl[e] = (T)sr;
+        if (f.telemetry_index >= 0) {
+            const size_t o = (size_t)f.telemetry_index * n_env + e;
+            f.total[o] = (T)total;
+            f.residual[o] = (T)resid;
+        }
+    }
 }
 
 template <typename T>
-int launch_recon_finish(const T* v, const int* act_idx, const T* action, T* coefs, T* obs, T* reward, int n_env,
-                        int n_act, int n_valid_act, double leak, int do_integrate, double gain_from_obs,
-                        hipStream_t st) {
-    hipLaunchKernelGGL(k_recon_finish<T>, dim3(n_env), dim3(256), (size_t)n_act * n_act * sizeof(T), st, v, act_idx, action, coefs, obs, reward,
-                       n_act, n_valid_act, (T)leak, do_integrate, (T)gain_from_obs);
-    AO_HIP(hipGetLastError());
-    return 0;
-}
-
-template <typename T>
-__global__ void k_copy_scal(const T* __restrict__ scal, T* __restrict__ d_strehl, int n_env) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < n_env) d_strehl[e] = scal[4 * e + 2];
-}
-template <typename T>
-int launch_copy_scal(const T* scal, T* d_strehl, int n_env, hipStream_t st) {
-    hipLaunchKernelGGL(k_copy_scal<T>, dim3(cdiv(n_env, 256)), dim3(256), 0, st, scal, d_strehl, n_env);
+int launch_recon_finish(const FinishArgs<T>& fa, int n_env, hipStream_t st) {
+    hipLaunchKernelGGL(k_recon_finish<T>, dim3(n_env), dim3(256), (size_t)fa.n_act * fa.n_act * sizeof(T), st, fa);
     AO_HIP(hipGetLastError());
     return 0;
 }
@@ -149,11 +248,9 @@ int launch_convert_from_f64(const double* src, T* dst, size_t n, hipStream_t st)
     return 0;
 }
 
-#define INST(T)                                                                                                  \
-    template int launch_gemm_nt<T>(const T*, const T*, T*, int, int, int, int, int, int, hipStream_t);           \
-    template int launch_recon_finish<T>(const T*, const int*, const T*, T*, T*, T*, int, int, int, double, int,  \
-                                        double, hipStream_t);                                                    \
-    template int launch_copy_scal<T>(const T*, T*, int, hipStream_t);                                            \
+#define INST(T)                                                                                        \
+    template int launch_gemm_nt<T>(const T*, const T*, T*, int, int, int, int, int, int, hipStream_t); \
+    template int launch_recon_finish<T>(const FinishArgs<T>&, int, hipStream_t);                       \
     template int launch_convert_from_f64<T>(const double*, T*, size_t, hipStream_t);
 INST(float)
 INST(double)

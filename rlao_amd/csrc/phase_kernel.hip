@@ -1,24 +1,35 @@
 // Residual-phase kernel: frozen-flow sub-pixel translation of every layer + footprint crop + layer sum
-// + deformable-mirror surface + pupil + phase scaling + the scalar telemetry reductions.
+// + deformable-mirror surface + pupil + phase scaling + partial sums of the scalar telemetry.
 //
-// Reference stages fused here (one workgroup per env):
+// Reference stages fused here:
 //   OOPAO/Atmosphere.py:406-407   layer.phase = warp(mapShift, translate(buff), order=3)[1:-1,1:-1]
 //   OOPAO/Atmosphere.py:439-450   phase_support += phase[footprint] * sqrt(fractionalR0)
 //   OOPAO/Atmosphere.py:474-477   OPD_no_pupil = phase_support * lambda_500 / 2 pi ; OPD = . * pupil
-//   MAIN/OOPAOEnv/OOPAOEnv.py:497 total[i] = std(tel.OPD[pupil]) * 1e9
 //   OOPAO/DeformableMirror.py:556 dm.OPD = modes @ coefs            (separable: Gy . C . Gx^T)
 //   OOPAO/DeformableMirror.py:469 + Telescope.py:540-542   OPD = (OPD_atm + dm.OPD) * pupil
 //   OOPAO/Telescope.py:404-412    src.phase = OPD * 2 pi / lambda_src
-//   MAIN/OOPAOEnv/OOPAOEnv.py:522,554-555  residual[i] = std(OPD[pupil])*1e9 ; strehl = exp(-var(phase[pupil]))
+//   MAIN/OOPAOEnv/OOPAOEnv.py:497,522,554-555  sums for total[i], residual[i], strehl (finished in the step epilogue)
+//
+// Launch shape: grid = (x tiles, y tiles, n_env), workgroup = 64 x 4 lanes; a tile is TX <= 128 columns by
+// TY = 16 rows, i.e. 8 pixels per lane and thousands of workgroups for a few hundred envs.
+//   * the layer tile (TY+3 rows x TX+3 columns: the 4 x 4 stencil apron) is staged in LDS with row-contiguous
+//     reads; the translation is the same for every pixel, so the Catmull-Rom interpolation is separable:
+//     one horizontal 4-tap pass into LDS, one vertical 4-tap pass into registers (8 taps instead of 16)
+//   * DM surface of the tile: s1 = Gy[tile rows] . C first (TY x nAct), then s1 . Gx^T per pixel: no work is
+//     repeated between tiles, and Gx^T of the tile's columns sits in LDS
+//   * Sum x, Sum x^2 of the atmosphere and residual OPD over the pupil are accumulated in float64 and
+//     written per tile; the epilogue kernel adds the tiles in a fixed order (bitwise reproducible).
 #include "common.hpp"
 
 namespace ao {
+
+constexpr int kTY = 16, kTXmax = 128;
 
 template <typename T>
 struct KArgs {
     PhaseArgs pa;
     PhaseBuffers<T> pb;
-    int R, n_act, n_valid_act, n_pupil, xchunk;
+    int R, n_act, n_valid_act, tx;
     T atm_scale;   // lambda_atm / 2 pi
     T src_scale;   // 2 pi / lambda_src
 };
@@ -29,162 +40,185 @@ __device__ inline double wave_sum(double v) {
 }
 
 template <typename T>
-__global__ void __launch_bounds__(1024) k_phase(const KArgs<T> a) {
+__global__ void __launch_bounds__(256) k_phase(const KArgs<T> a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    T* cimg = reinterpret_cast<T*>(lds_raw);            // [n_act][n_act] command image
-    T* t1 = cimg + a.n_act * a.n_act;                   // [n_act][xchunk]  C . Gx^T for one column chunk
-    __shared__ double red[4][16];
+    const int R = a.R, nA = a.n_act, S = a.pa.S, TX = a.tx;
+    const int MW = TX + 4;                                   // row stride of the staged layer tile (TX + 3 used)
+    T* cimg = reinterpret_cast<T*>(lds_raw);                 // [nA][nA]
+    T* s1 = cimg + nA * nA;                                  // [kTY][nA]
+    T* gxt = s1 + kTY * nA;                                  // [nA][TX]
+    T* mapt = gxt + nA * TX;                                 // [kTY + 3][MW]
+    T* ht = mapt + (kTY + 3) * MW;                           // [kTY + 3][TX]
+    __shared__ double red[4][4];
 
-    const int e = blockIdx.x;
-    const int R = a.R, nA = a.n_act, S = a.pa.S;
+    const int e = blockIdx.z;
+    const int x0 = blockIdx.x * TX, y0 = blockIdx.y * kTY;
+    const int txe = min(TX, R - x0), tye = min(kTY, R - y0);
+    const int lx = threadIdx.x, ly = threadIdx.y, tid = ly * 64 + lx;
     const size_t pix0 = (size_t)e * R * R;
     const bool separable = (a.pb.dm_opd == nullptr);
 
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) a.pb.wfs_max[e] = (T)0;
+
     if (separable) {
-        for (int i = threadIdx.x; i < nA * nA; i += blockDim.x) cimg[i] = (T)0;
+        for (int i = tid; i < nA * nA; i += 256) cimg[i] = (T)0;
         __syncthreads();
         const T* cf = a.pb.coefs + (size_t)e * a.n_valid_act;
-        for (int k = threadIdx.x; k < a.n_valid_act; k += blockDim.x) cimg[a.pb.act_idx[k]] = cf[k];
-    }
-    if (threadIdx.x == 0) a.pb.wfs_max[e] = (T)0;
-
-    double s_atm = 0.0, q_atm = 0.0, s_res = 0.0, q_res = 0.0;
-
-    for (int x0 = 0; x0 < R; x0 += a.xchunk) {
-        const int xw = min(a.xchunk, R - x0);
+        for (int k = tid; k < a.n_valid_act; k += 256) cimg[a.pb.act_idx[k]] = cf[k];
+        // Gx^T of this tile's columns (global reads run along ix then x: contiguous)
+        for (int i = tid; i < txe * nA; i += 256) {
+            const int x = i / nA, ix = i - x * nA;
+            gxt[ix * TX + x] = a.pb.gx[(size_t)(x0 + x) * nA + ix];
+        }
         __syncthreads();
-        if (separable) {
-            // t1[iy][x] = sum_ix C[iy][ix] * gx[x][ix]
-            for (int i = threadIdx.x; i < nA * xw; i += blockDim.x) {
-                const int iy = i / xw, x = i % xw;
-                const T* g = a.pb.gx + (size_t)(x0 + x) * nA;
-                const T* c = cimg + iy * nA;
-                T acc = (T)0;
-                for (int ix = 0; ix < nA; ++ix) acc += c[ix] * g[ix];
-                t1[iy * a.xchunk + x] = acc;
+        // s1[y][ix] = sum_iy gy[y0 + y][iy] * C[iy][ix]
+        for (int i = tid; i < tye * nA; i += 256) {
+            const int y = i / nA, ix = i - y * nA;
+            const T* g = a.pb.gy + (size_t)(y0 + y) * nA;
+            T acc = (T)0;
+            for (int iy = 0; iy < nA; ++iy) acc += g[iy] * cimg[iy * nA + ix];
+            s1[y * nA + ix] = acc;
+        }
+    }
+
+    // this lane's pixels: x = lx + 64 i (i < 2), y = ly + 4 j (j < 4)
+    T sup[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sup[i][j] = (T)0;
+
+    if (a.pa.update_atm) {
+        for (int l = 0; l < a.pa.n_layer; ++l) {
+            const LayerTaps& tp = a.pa.taps[l];
+            const T* map = static_cast<const T*>(a.pa.screen[l]) + (size_t)e * S * S;
+            const int r0 = y0 + a.pa.foot + tp.dy - 1, c0 = x0 + a.pa.foot + tp.dx - 1;
+            __syncthreads();                                  // previous layer's tiles are no longer read
+            for (int r = ly; r < tye + 3; r += 4) {
+                const int rr = r0 + r;
+                for (int c = lx; c < txe + 3; c += 64) {
+                    const int cc = c0 + c;
+                    mapt[r * MW + c] = (rr >= 0 && rr < S && cc >= 0 && cc < S) ? map[(size_t)rr * S + cc] : (T)0;
+                }
             }
             __syncthreads();
-        }
-        for (int i = threadIdx.x; i < R * xw; i += blockDim.x) {
-            const int y = i / xw, xl = i % xw, x = x0 + xl;
-            const size_t p = pix0 + (size_t)y * R + x;
-            T atm;
-            if (a.pa.update_atm) {
-                T sup = (T)0;
-                for (int l = 0; l < a.pa.n_layer; ++l) {
-                    const LayerTaps& tp = a.pa.taps[l];
-                    const T* map = static_cast<const T*>(a.pa.screen[l]) + (size_t)e * S * S;
-                    const int r0 = y + a.pa.foot + tp.dy - 1, c0 = x + a.pa.foot + tp.dx - 1;
-                    T v = (T)0;
+            const T wx0 = (T)tp.wx[0], wx1 = (T)tp.wx[1], wx2 = (T)tp.wx[2], wx3 = (T)tp.wx[3];
+            for (int r = ly; r < tye + 3; r += 4) {
+                const T* m = mapt + r * MW;
+                for (int x = lx; x < txe; x += 64)
+                    ht[r * TX + x] = ((wx0 * m[x] + wx1 * m[x + 1]) + wx2 * m[x + 2]) + wx3 * m[x + 3];
+            }
+            __syncthreads();
+            const T wy0 = (T)tp.wy[0], wy1 = (T)tp.wy[1], wy2 = (T)tp.wy[2], wy3 = (T)tp.wy[3];
+            const T* mm = static_cast<const T*>(a.pa.minmax[l]) + 2 * e;
+            const T lo = mm[0], hi = mm[1], wl = (T)tp.weight;
+            const bool zero_outside = (lo > (T)0 || hi < (T)0);
 #pragma unroll
-                    for (int pr = 0; pr < 4; ++pr) {
-                        const int rr = r0 + pr;
-                        T row = (T)0;
-                        if (rr >= 0 && rr < S) {
-                            const T* m = map + (size_t)rr * S;
+            for (int i = 0; i < 2; ++i) {
+                const int x = lx + 64 * i;
 #pragma unroll
-                            for (int pc = 0; pc < 4; ++pc) {
-                                const int cc = c0 + pc;
-                                const T f = (cc >= 0 && cc < S) ? m[cc] : (T)0;
-                                row += (T)tp.wx[pc] * f;
-                            }
-                        }
-                        v += (T)tp.wy[pr] * row;
+                for (int j = 0; j < 4; ++j) {
+                    const int y = ly + 4 * j;
+                    if (x < txe && y < tye) {
+                        const T* h = ht + y * TX + x;
+                        T v = ((wy0 * h[0] + wy1 * h[TX]) + wy2 * h[2 * TX]) + wy3 * h[3 * TX];
+                        // skimage clip=True: clamp to the input range, keep exact zeros when 0 is outside it
+                        if (!(zero_outside && v == (T)0)) v = v < lo ? lo : (v > hi ? hi : v);
+                        sup[i][j] += v * wl;
                     }
-                    // skimage clip=True: clamp to the input range, keep exact zeros when 0 is outside it
-                    const T* mm = static_cast<const T*>(a.pa.minmax[l]) + 2 * e;
-                    const T lo = mm[0], hi = mm[1];
-                    if (!((lo > (T)0 || hi < (T)0) && v == (T)0)) v = v < lo ? lo : (v > hi ? hi : v);
-                    sup += v * (T)tp.weight;
                 }
-                atm = sup * a.atm_scale;
-                a.pb.opd_atm[p] = atm;
-            } else {
-                atm = a.pb.opd_atm[p];
-            }
-            T dm;
-            if (separable) {
-                const T* g = a.pb.gy + (size_t)y * nA;
-                dm = (T)0;
-                for (int iy = 0; iy < nA; ++iy) dm += g[iy] * t1[iy * a.xchunk + xl];
-            } else {
-                dm = a.pb.dm_opd[p];
-            }
-            const bool in = a.pb.pupil[(size_t)y * R + x] != 0;
-            const T res = in ? (atm + dm) : (T)0;
-            a.pb.phase[p] = res * a.src_scale;
-            if (in) {
-                const double da = (double)atm, dr = (double)res;
-                s_atm += da;
-                q_atm += da * da;
-                s_res += dr;
-                q_res += dr * dr;
             }
         }
     }
+    __syncthreads();                                          // s1 / gxt complete (and tiles done)
 
+    double s_atm = 0.0, q_atm = 0.0, s_res = 0.0, q_res = 0.0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int x = lx + 64 * i;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int y = ly + 4 * j;
+            if (x < txe && y < tye) {
+                const size_t q = (size_t)(y0 + y) * R + (x0 + x);
+                T atm;
+                if (a.pa.update_atm) {
+                    atm = sup[i][j] * a.atm_scale;
+                    a.pb.opd_atm[pix0 + q] = atm;
+                } else {
+                    atm = a.pb.opd_atm[pix0 + q];
+                }
+                T dm;
+                if (separable) {
+                    dm = (T)0;
+                    const T* sr = s1 + y * nA;
+                    for (int ix = 0; ix < nA; ++ix) dm += sr[ix] * gxt[ix * TX + x];
+                } else {
+                    dm = a.pb.dm_opd[pix0 + q];
+                }
+                const bool in = a.pb.pupil[q] != 0;
+                const T res = in ? (atm + dm) : (T)0;
+                a.pb.phase[pix0 + q] = res * a.src_scale;
+                if (in) {
+                    const double da = (double)atm, dr = (double)res;
+                    s_atm += da;
+                    q_atm += da * da;
+                    s_res += dr;
+                    q_res += dr * dr;
+                }
+            }
+        }
+    }
     s_atm = wave_sum(s_atm);
     q_atm = wave_sum(q_atm);
     s_res = wave_sum(s_res);
     q_res = wave_sum(q_res);
-    const int w = threadIdx.x / kWave;
-    if ((threadIdx.x & (kWave - 1)) == 0) {
-        red[0][w] = s_atm;
-        red[1][w] = q_atm;
-        red[2][w] = s_res;
-        red[3][w] = q_res;
+    if (lx == 0) {
+        red[0][ly] = s_atm;
+        red[1][ly] = q_atm;
+        red[2][ly] = s_res;
+        red[3][ly] = q_res;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double v[4] = {0, 0, 0, 0};
-        for (int k = 0; k < 4; ++k)
-            for (int i = 0; i < (int)blockDim.x / kWave; ++i) v[k] += red[k][i];
-        const double n = (double)a.n_pupil;
-        double var_atm = v[1] / n - (v[0] / n) * (v[0] / n);
-        double var_res = v[3] / n - (v[2] / n) * (v[2] / n);
-        var_atm = var_atm > 0 ? var_atm : 0;
-        var_res = var_res > 0 ? var_res : 0;
-        const double total = sqrt(var_atm) * 1e9, resid = sqrt(var_res) * 1e9;
-        const double k2 = (double)a.src_scale * (double)a.src_scale;
-        T* sc = a.pb.scal + 4 * e;
-        sc[0] = (T)total;
-        sc[1] = (T)resid;
-        sc[2] = (T)exp(-var_res * k2);
-        if (a.pa.telemetry_index >= 0) {
-            const size_t o = (size_t)a.pa.telemetry_index * gridDim.x + e;
-            a.pb.total[o] = (T)total;
-            a.pb.residual[o] = (T)resid;
-        }
+    if (tid < 4) {
+        const int tile = blockIdx.y * gridDim.x + blockIdx.x, n_tiles = gridDim.x * gridDim.y;
+        a.pb.part[((size_t)e * n_tiles + tile) * 4 + tid] = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
     }
+}
+
+int phase_tiles(int R) {
+    const int tx = R < kTXmax ? R : kTXmax;
+    return cdiv(R, tx) * cdiv(R, kTY);
 }
 
 template <typename T>
 int launch_phase(const PhaseArgs& pa, const PhaseBuffers<T>& pb, int n_env, int R, int n_act, int n_valid_act,
-                 int n_pupil, double atm_wavelength, double src_wavelength, hipStream_t st) {
+                 double atm_wavelength, double src_wavelength, hipStream_t st) {
     KArgs<T> a;
     a.pa = pa;
     a.pb = pb;
     a.R = R;
     a.n_act = n_act;
     a.n_valid_act = n_valid_act;
-    a.n_pupil = n_pupil;
-    const double two_pi = 6.283185307179586476925286766559;
+    a.tx = R < kTXmax ? R : kTXmax;
     a.atm_scale = (T)(atm_wavelength / 2 / 3.14159265358979323846);
-    a.src_scale = (T)(two_pi / src_wavelength);
-    // column chunk so that the C.Gx^T slab stays within 48 KiB of LDS
-    int xchunk = R;
-    const size_t budget = 48 * 1024;
-    while ((size_t)n_act * xchunk * sizeof(T) > budget && xchunk > 8) xchunk = (xchunk + 1) / 2;
-    a.xchunk = xchunk;
-    const size_t lds = ((size_t)n_act * n_act + (size_t)n_act * xchunk) * sizeof(T);
-    hipLaunchKernelGGL(k_phase<T>, dim3(n_env), dim3(1024), lds, st, a);
+    a.src_scale = (T)(6.283185307179586476925286766559 / src_wavelength);
+    const int TX = a.tx, MW = TX + 4;
+    const size_t lds = sizeof(T) * ((size_t)n_act * n_act + (size_t)kTY * n_act + (size_t)n_act * TX +
+                                    (size_t)(kTY + 3) * MW + (size_t)(kTY + 3) * TX);
+    if (lds > 160 * 1024) return fail("phase kernel: %d actuators across need %zu B of LDS", n_act, lds);
+    if (lds > 64 * 1024)
+        AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_phase<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds));
+    dim3 grid(cdiv(R, TX), cdiv(R, kTY), n_env);
+    hipLaunchKernelGGL(k_phase<T>, grid, dim3(64, 4), lds, st, a);
     AO_HIP(hipGetLastError());
     return 0;
 }
 
-template int launch_phase<float>(const PhaseArgs&, const PhaseBuffers<float>&, int, int, int, int, int, double,
-                                 double, hipStream_t);
-template int launch_phase<double>(const PhaseArgs&, const PhaseBuffers<double>&, int, int, int, int, int, double,
-                                  double, hipStream_t);
+template int launch_phase<float>(const PhaseArgs&, const PhaseBuffers<float>&, int, int, int, int, double, double,
+                                 hipStream_t);
+template int launch_phase<double>(const PhaseArgs&, const PhaseBuffers<double>&, int, int, int, int, double, double,
+                                  hipStream_t);
 
 }  // namespace ao

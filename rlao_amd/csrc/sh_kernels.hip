@@ -111,10 +111,172 @@ __global__ void __launch_bounds__(256) k_sh_spots(const T* __restrict__ phase, c
     if (active && lane == 0) atomic_max_nonneg(&wfs_max[e], mx);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Fast path for P = 6 pixels per lenslet (n = 12): every BASELINE configuration.
+//
+// One wavefront per ROW of lenslets; P/2 = 3 lanes per lenslet, 21 lenslets per pass.  Lane (j, q) owns
+// the spectral columns v in {2q, 2q+1, 2q+6, 2q+7}, i.e. the two camera columns Q = q and Q = q+3.
+//   stage 0  the wave reads its P x (21 P) strip of phase / amplitude with coalesced row loads, turns it
+//            into E0 = amp e^{i phi} and parks it in LDS laid out per lenslet (stride 37: bank-conflict free)
+//   stage 1  G[a][v] = sum_b E0[a][b] (ph_b w^{(b+lo) v})     per-lane twiddle registers (depend on q)
+//            columns v and v+6 share their products: w^{(b+lo)(v+6)} = (-1)^{b+lo} w^{(b+lo) v}
+//   stage 2  F[u][v] = sum_a (ph_a w^{u (a+lo)}) G[a][v]      compile-time twiddles; rows u and u+6 share
+//   binning  I[P][Q] = sum_{du,dv} |F[2P+du][2Q+dv]|^2 / n^2  entirely in the lane's registers
+//   output   the strip of the camera frame is staged in LDS and written as whole rows; one atomicMax per wave
+// All arithmetic after stage 0 is register-resident FMAs (~2.6 kFMA per lenslet instead of 5.2 k), and the
+// centring phasor exp(-i pi (n+1)/n (x+y)) = ph_a ph_b is folded into the twiddles.
+// ---------------------------------------------------------------------------------------------------
+namespace fast6 {
+constexpr int P = 6, N = 12, LO = 3, HP = 3, SPW = 21, EST = P * P + 1;
+// cos(k pi / 12), k = 0 .. 23
+__device__ constexpr double kCos[24] = {
+    1.0, 0.96592582628906829, 0.86602540378443865, 0.70710678118654752, 0.5, 0.25881904510252076,
+    0.0, -0.25881904510252076, -0.5, -0.70710678118654752, -0.86602540378443865, -0.96592582628906829,
+    -1.0, -0.96592582628906829, -0.86602540378443865, -0.70710678118654752, -0.5, -0.25881904510252076,
+    0.0, 0.25881904510252076, 0.5, 0.70710678118654752, 0.86602540378443865, 0.96592582628906829};
+// exp(-i pi m / 12)
+__device__ constexpr double cre(int m) { return kCos[((m % 24) + 24) % 24]; }
+__device__ constexpr double cim(int m) { return -kCos[((((m % 24) + 24) % 24) + 18) % 24]; }   // -sin(x) = -cos(x - pi/2)
+// stage-2 twiddle ph_a w^{u(a+lo)} = exp(-i pi (a+lo)(13 + 2u)/12)
+__device__ constexpr int k2(int u, int a) { return (a + LO) * (13 + 2 * u); }
+}  // namespace fast6
+
+template <typename T>
+__global__ void __launch_bounds__(128, 2) k_sh_spots_p6(const T* __restrict__ phase, const ShConst<T> sc,
+                                                     const uint8_t* __restrict__ valid2d, T* __restrict__ frame,
+                                                     T* __restrict__ wfs_max, int R, int n_subap) {
+    using namespace fast6;
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
+    constexpr int W = SPW * P;                                        // strip width in pixels
+    cplx<T>* Ew = reinterpret_cast<cplx<T>*>(lds_raw) + wave * (SPW * EST);
+    T* Fs = reinterpret_cast<T*>(reinterpret_cast<cplx<T>*>(lds_raw) + 2 * (SPW * EST)) + wave * (P * W);
+
+    const int e = blockIdx.y;
+    const int i = blockIdx.x * 2 + wave;                              // lenslet row of this wave
+    const bool row_ok = i < n_subap;
+    const T* ph = phase + (size_t)e * R * R;
+    T* fr = frame + (size_t)e * R * R;
+    const int jl = lane / HP, q = lane - jl * HP;
+
+    T mx = 0;
+    for (int j0 = 0; j0 < n_subap; j0 += SPW) {
+        // ---- stage 0: strip of phase -> E0 in LDS ------------------------------------------------------
+        for (int t = lane; t < P * W; t += kWave) {
+            const int b = t / W, c = t - b * W;
+            const int col = j0 * P + c;
+            T er = 0, ei = 0;
+            if (row_ok && col < R) {
+                const int pix = (i * P + b) * R + col;
+                const T am = sc.amp[pix];
+                if (am != (T)0) {
+                    T sn, cs;
+                    sincos_t<T>(ph[pix], &sn, &cs);
+                    er = am * cs;
+                    ei = am * sn;
+                }
+            }
+            const int jj = c / P, a = c - jj * P;
+            Ew[jj * EST + a * P + b] = {er, ei};
+        }
+        __syncthreads();
+
+        const int j = j0 + jl;
+        const bool ok = row_ok && lane < SPW * HP && j < n_subap && valid2d[i * n_subap + j] != 0;
+        T Ia[P], Ib[P];
+#pragma unroll
+        for (int u = 0; u < P; ++u) Ia[u] = Ib[u] = (T)0;
+        if (ok) {
+            const cplx<T>* Ej = Ew + jl * EST;
+            const T inv_n2 = (T)(1.0 / (N * N));
+            // the two spectral columns v = 2q + c, c = 0, 1 (and their partners v + 6) one after the other:
+            // keeps only 2 x 6 complex G values live (register pressure decides the occupancy here)
+#pragma unroll 1
+            for (int c = 0; c < 2; ++c) {
+                // stage-1 twiddles ph_b w^{(b+lo) v} = exp(-i pi (b+lo)(13 + 2 v)/12) of this lane's column
+                T t1r[P], t1i[P];
+#pragma unroll
+                for (int b = 0; b < P; ++b) {
+                    const int m = ((b + LO) * (13 + 2 * (2 * q + c))) % 24;
+                    t1r[b] = (T)kCos[m];
+                    t1i[b] = (T)(-kCos[(m + 18) % 24]);
+                }
+                T G0r[P], G0i[P], G1r[P], G1i[P];                      // columns v and v + 6
+#pragma unroll
+                for (int a = 0; a < P; ++a) {
+                    T evr = 0, evi = 0, odr = 0, odi = 0;              // b + lo even: b = 1, 3, 5 ; odd: b = 0, 2, 4
+#pragma unroll
+                    for (int b = 0; b < P; ++b) {
+                        const cplx<T> x = Ej[a * P + b];
+                        const T pr = x.re * t1r[b] - x.im * t1i[b];
+                        const T pi = x.re * t1i[b] + x.im * t1r[b];
+                        if ((b + LO) % 2 == 0) { evr += pr; evi += pi; } else { odr += pr; odi += pi; }
+                    }
+                    G0r[a] = evr + odr; G0i[a] = evi + odi;
+                    G1r[a] = evr - odr; G1i[a] = evi - odi;
+                }
+                // stage 2 (compile-time twiddles) + binning; rows u and u + 6 share their products
+#pragma unroll
+                for (int u = 0; u < P; ++u) {
+                    T e0r = 0, e0i = 0, o0r = 0, o0i = 0, e1r = 0, e1i = 0, o1r = 0, o1i = 0;
+#pragma unroll
+                    for (int a = 0; a < P; ++a) {
+                        const T kr = (T)cre(k2(u, a)), ki = (T)cim(k2(u, a));
+                        const T p0r = G0r[a] * kr - G0i[a] * ki, p0i = G0r[a] * ki + G0i[a] * kr;
+                        const T p1r = G1r[a] * kr - G1i[a] * ki, p1i = G1r[a] * ki + G1i[a] * kr;
+                        if ((a + LO) % 2 == 0) { e0r += p0r; e0i += p0i; e1r += p1r; e1i += p1i; }
+                        else { o0r += p0r; o0i += p0i; o1r += p1r; o1i += p1i; }
+                    }
+                    T fr_, fi_;
+                    fr_ = e0r + o0r; fi_ = e0i + o0i; Ia[u / 2] += (fr_ * fr_ + fi_ * fi_) * inv_n2;        // (u, v)
+                    fr_ = e0r - o0r; fi_ = e0i - o0i; Ia[u / 2 + 3] += (fr_ * fr_ + fi_ * fi_) * inv_n2;    // (u+6, v)
+                    fr_ = e1r + o1r; fi_ = e1i + o1i; Ib[u / 2] += (fr_ * fr_ + fi_ * fi_) * inv_n2;        // (u, v+6)
+                    fr_ = e1r - o1r; fi_ = e1i - o1i; Ib[u / 2 + 3] += (fr_ * fr_ + fi_ * fi_) * inv_n2;    // (u+6, v+6)
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < P; ++u) {
+                mx = Ia[u] > mx ? Ia[u] : mx;
+                mx = Ib[u] > mx ? Ib[u] : mx;
+            }
+        }
+        // ---- stage the camera strip and write whole rows ------------------------------------------------------
+        if (lane < SPW * HP) {
+#pragma unroll
+            for (int u = 0; u < P; ++u) {
+                Fs[u * W + jl * P + q] = Ia[u];
+                Fs[u * W + jl * P + q + 3] = Ib[u];
+            }
+        }
+        __syncthreads();
+        if (row_ok) {
+            for (int t = lane; t < P * W; t += kWave) {
+                const int u = t / W, c = t - u * W;
+                const int col = j0 * P + c;
+                if (col < R) fr[(size_t)(i * P + u) * R + col] = Fs[t];
+            }
+        }
+        __syncthreads();
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const T o = __shfl_down(mx, off);
+        mx = o > mx ? o : mx;
+    }
+    if (row_ok && lane == 0) atomic_max_nonneg(&wfs_max[e], mx);
+}
+
 template <typename T>
 int launch_sh_spots(const T* phase, const ShConst<T>& sc, T* frame, T* wfs_max, int n_env, int R, int n_subap,
                     int n_valid, hipStream_t st) {
     const int p = R / n_subap, n = 2 * p;
+    if (p == fast6::P && sc.valid2d != nullptr) {
+        const size_t lds6 = 2 * (sizeof(cplx<T>) * fast6::SPW * fast6::EST + sizeof(T) * fast6::P * fast6::SPW * fast6::P);
+        dim3 grid6(cdiv(n_subap, 2), n_env);
+        hipLaunchKernelGGL(k_sh_spots_p6<T>, grid6, dim3(128), lds6, st, phase, sc, sc.valid2d, frame, wfs_max, R,
+                           n_subap);
+        AO_HIP(hipGetLastError());
+        return 0;
+    }
     const size_t lds = sizeof(cplx<T>) * (n + 4 * (p * p + p * n));
     if (lds > 64 * 1024) return fail("sh_spots: %d px per lenslet needs %zu B of LDS", p, lds);
     dim3 grid(cdiv(n_valid, 4), n_env);
