@@ -177,7 +177,10 @@ int aoenv_set_buff(AoEnv* env, const double* h_buff);
 /* Implementation switches (parity tests compare the specialised kernels with the generic ones). */
 enum AoOption {
     AOENV_OPT_FAST_WFS = 0,  /* 1 (default): register-resident 6 px/lenslet SH kernel; 0: generic LDS kernel */
-    AOENV_OPT_MFMA_GEMM = 1  /* 1 (default): float32 split-K MFMA contractions; 0: generic tiled VALU kernel */
+    AOENV_OPT_MFMA_GEMM = 1, /* 1 (default): float32 split-K MFMA contractions; 0: generic tiled VALU kernel */
+    AOENV_OPT_STORE_ATM_OPD = 3, /* 1: every step also writes atm.OPD_no_pupil to AOENV_B_OPD_ATM; 0 (default): it is
+                                re-derived from the screens when it is downloaded */
+    AOENV_OPT_FAST_TRIG = 2  /* 1 (default): v_sin/v_cos after Cody-Waite reduction in the float32 SH kernel; 0: sincosf */
 };
 int aoenv_set_option(AoEnv* env, int option, int value);
 

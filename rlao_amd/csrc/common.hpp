@@ -49,7 +49,9 @@ struct PhaseArgs {
     int n_layer;
     int S;                           // N + 2
     int foot;                        // offset of the R x R pupil footprint inside the (N+2)^2 screen
-    int update_atm;                  // 1: recompute opd_atm from the screens; 0: keep the buffer
+    int update_atm;                  // 1: atmosphere OPD from the screens; 0: from the opd_atm buffer (user-defined OPD)
+    int store_atm;                   // 1: also write atm.OPD_no_pupil to the opd_atm buffer (state inspection)
+    int store_phase;                 // 0: leave the residual phase, the telemetry sums and wfs_max untouched
 };
 
 }  // namespace ao
@@ -81,6 +83,7 @@ struct PhaseBuffers {
     const T* dm_opd;       // [E][R*R] (dense DM path) or nullptr
     const T* gx;           // [R][nAct]
     const T* gy;           // [R][nAct]
+    const T* gxt;          // [nActPad4][Rpad128] zero-padded transpose of gx (MFMA B operand), may be null
     const int* act_idx;    // [A]
     const uint8_t* pupil;  // [R*R]
     T* phase;              // [E][R*R]
@@ -90,7 +93,7 @@ struct PhaseBuffers {
 int phase_tiles(int R);
 template <typename T>
 int launch_phase(const PhaseArgs& pa, const PhaseBuffers<T>& pb, int n_env, int R, int n_act, int n_valid_act,
-                 double atm_wavelength, double src_wavelength, hipStream_t st);
+                 double atm_wavelength, double src_wavelength, int use_mfma, hipStream_t st);
 
 template <typename T>
 struct ShConst {
@@ -102,6 +105,7 @@ struct ShConst {
     const T* ph;             // [p][2]   phasor at padded coordinate a + lo
     T units;                 // slopes_units
     T threshold;
+    int fast_trig;           // 1: hardware sin/cos after Cody-Waite reduction (float32 shards only)
 };
 template <typename T>
 int launch_sh_spots(const T* phase, const ShConst<T>& sc, T* frame, T* wfs_max, int n_env, int R, int n_subap,

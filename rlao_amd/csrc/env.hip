@@ -53,6 +53,7 @@ struct AoEnv {
     double layer_weight[kMaxLayer] = {0};
     void* gx = nullptr;
     void* gy = nullptr;
+    void* gxt = nullptr;                    // [nActPad4][Rpad128] transpose of gx, zero padded
     void* modes = nullptr;                  // [R*R][A]
     void* dm_opd = nullptr;                 // [E][R*R] dense path
     int* act_idx = nullptr;
@@ -81,6 +82,10 @@ struct AoEnv {
     // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
     bool use_fast_wfs = true;               // aoenv_set_option(AOENV_OPT_FAST_WFS)
     bool use_mfma = true;                   // aoenv_set_option(AOENV_OPT_MFMA_GEMM)
+    bool use_fast_trig = true;              // aoenv_set_option(AOENV_OPT_FAST_TRIG)
+    bool store_opd_atm = false;             // aoenv_set_option(AOENV_OPT_STORE_ATM_OPD): write atm.OPD every step
+    bool atm_user_defined = false;          // aoenv_set_atm_opd() until the next step / new screens
+    int debug_ablate = 0;                   // aoenv_set_option(99): skip kernel sections (timing diagnosis only)
     bool prof_on = false;
     struct ProfEv { int stage; hipEvent_t a, b; };
     std::vector<ProfEv> prof_ev;
@@ -159,6 +164,7 @@ ShConst<T> sh_const(const AoEnv* env) {
     sc.ph = env->as<T>(env->phs);
     sc.units = (T)env->units;
     sc.threshold = (T)env->c.threshold_cog;
+    sc.fast_trig = (env->use_fast_trig && sizeof(T) == 4) ? 1 : 0;
     return sc;
 }
 
@@ -235,12 +241,14 @@ int advance_atmosphere(AoEnv* env, hipStream_t st) {
 }
 
 template <typename T>
-int run_phase(AoEnv* env, int update_atm, hipStream_t st) {
+int run_phase(AoEnv* env, int update_atm, int store_atm, hipStream_t st, int store_phase = 1) {
     PhaseArgs pa{};
     pa.n_layer = env->L;
     pa.S = env->S;
     pa.foot = (env->N / 2 - env->R / 2) + 1;
-    pa.update_atm = (update_atm && env->L > 0) ? 1 : 0;
+    pa.update_atm = (update_atm && env->L > 0 && !env->atm_user_defined) ? 1 : 0;
+    pa.store_atm = store_atm;
+    pa.store_phase = store_phase;
     for (int l = 0; l < env->L; ++l) {
         pa.screen[l] = env->screen_ptr(env->cur[l], l);
         pa.minmax[l] = env->minmax_ptr(l);
@@ -259,6 +267,7 @@ int run_phase(AoEnv* env, int update_atm, hipStream_t st) {
     pb.dm_opd = env->c.dm_separable ? nullptr : env->as<T>(env->dm_opd);
     pb.gx = env->as<T>(env->gx);
     pb.gy = env->as<T>(env->gy);
+    pb.gxt = env->as<T>(env->gxt);
     pb.act_idx = env->act_idx;
     pb.pupil = env->pupil;
     pb.phase = env->as<T>(env->phase);
@@ -266,7 +275,7 @@ int run_phase(AoEnv* env, int update_atm, hipStream_t st) {
     pb.wfs_max = env->as<T>(env->wfs_max);
     AO_PROF(env, PHASE, st);
     return launch_phase<T>(pa, pb, env->E, env->R, env->nAct, env->A, env->c.atm_wavelength, env->c.src_wavelength,
-                           st);
+                           (env->use_mfma ? 1 : 0) | (env->debug_ablate << 8), st);
 }
 
 template <typename T>
@@ -336,7 +345,8 @@ template <typename T>
 int step_t(AoEnv* env, int i, const void* d_action, void* d_obs, void* d_frame, void* d_reward, void* d_strehl,
            double gain, hipStream_t st) {
     AO_TRY(advance_atmosphere<T>(env, st));
-    AO_TRY(run_phase<T>(env, 1, st));
+    env->atm_user_defined = false;
+    AO_TRY(run_phase<T>(env, 1, env->store_opd_atm ? 1 : 0, st));
     AO_TRY(run_wfs<T>(env, st));
     AO_TRY(run_recon<T>(env, static_cast<const T*>(d_action), static_cast<T*>(d_obs), static_cast<T*>(d_reward),
                         static_cast<T*>(d_strehl), i, 1, gain, st));
@@ -427,6 +437,7 @@ int aoenv_create(const AoCfg* cfg, int device, AoEnv** out) {
     }
     A_(&e->gx, (size_t)e->R * e->nAct * z);
     A_(&e->gy, (size_t)e->R * e->nAct * z);
+    A_(&e->gxt, (size_t)((e->nAct + 3) & ~3) * (size_t)(cdiv(e->R, 128) * 128) * z);
     if (!cfg->dm_separable) {
         A_(&e->modes, R2 * e->A * z);
         A_(&e->dm_opd, E * R2 * z);
@@ -527,6 +538,13 @@ int aoenv_upload(AoEnv* env, int kind, const void* h, size_t bytes) {
         case AOENV_C_DM_GY:
             AO_TRY(need((size_t)env->R * env->nAct * 8));
             AO_TRY(upload_real(env, kind == AOENV_C_DM_GX ? env->gx : env->gy, d, (size_t)env->R * env->nAct));
+            if (kind == AOENV_C_DM_GX) {
+                const int nap = (env->nAct + 3) & ~3, rp = cdiv(env->R, 128) * 128;
+                std::vector<double> t((size_t)nap * rp, 0.0);
+                for (int x = 0; x < env->R; ++x)
+                    for (int ix = 0; ix < env->nAct; ++ix) t[(size_t)ix * rp + x] = d[(size_t)x * env->nAct + ix];
+                AO_TRY(upload_real(env, env->gxt, t.data(), t.size()));
+            }
             break;
         case AOENV_C_DM_MODES:
             if (env->c.dm_separable) return fail("dense modes uploaded to a separable-DM shard");
@@ -633,7 +651,8 @@ int aoenv_new_screens(AoEnv* env, const double* h_screens, const uint32_t* h_rin
         env->clk[l].buff[0] = env->clk[l].buff[1] = 0;            // notDoneOnce (OOPAO/Atmosphere.py:586, 359-364)
         AO_TRY(AO_DISPATCH(env, extrude, env, l, 0, 0, false, st));
     }
-    AO_TRY(AO_DISPATCH(env, run_phase, env, 1, st));               // fill_phase_support + set_OPD + atm*tel
+    env->atm_user_defined = false;
+    AO_TRY(AO_DISPATCH(env, run_phase, env, 1, 1, st));            // fill_phase_support + set_OPD + atm*tel
     return 0;
 }
 
@@ -642,6 +661,7 @@ int aoenv_set_atm_opd(AoEnv* env, const double* h_opd, void* stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     AO_HIP(hipStreamSynchronize(st));
     const size_t n = (size_t)env->E * env->R * env->R;
+    env->atm_user_defined = true;
     if (!h_opd) { AO_HIP(hipMemset(env->opd_atm, 0, n * env->esz)); return 0; }
     return upload_real(env, env->opd_atm, h_opd, n);
 }
@@ -660,7 +680,7 @@ int aoenv_measure(AoEnv* env, void* stream) {
     AO_CHECK_ENV(env);
     AO_TRY(require_step_constants(env, false));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    AO_TRY(AO_DISPATCH(env, run_phase, env, 0, st));
+    AO_TRY(AO_DISPATCH(env, run_phase, env, 1, 1, st));            // atmosphere re-derived from the screens at the current buff
     return AO_DISPATCH(env, run_wfs, env, st);
 }
 
@@ -723,6 +743,12 @@ int aoenv_download(AoEnv* env, int which, void* h_dst, size_t bytes, void* strea
             AO_HIP(hipMemcpy(static_cast<char*>(h_dst) + l * per, env->screen_ptr(env->cur[l], l), per, hipMemcpyDeviceToHost));
         return 0;
     }
+    if (which == AOENV_B_OPD_ATM && env->L > 0 && !env->atm_user_defined && !env->store_opd_atm) {
+        // not written by the step kernels unless AOENV_OPT_STORE_ATM_OPD: re-derive it from the screens now
+        // (same kernel, same sampling constants; the residual phase it rewrites is identical)
+        AO_TRY(AO_DISPATCH(env, run_phase, env, 1, 1, st, 0));
+        AO_HIP(hipStreamSynchronize(st));
+    }
     AO_HIP(hipMemcpy(h_dst, b.ptr, bytes, hipMemcpyDeviceToHost));
     return 0;
 }
@@ -760,6 +786,9 @@ int aoenv_set_option(AoEnv* env, int option, int value) {
     switch (option) {
         case AOENV_OPT_FAST_WFS: env->use_fast_wfs = value != 0; return 0;
         case AOENV_OPT_MFMA_GEMM: env->use_mfma = value != 0; return 0;
+        case AOENV_OPT_FAST_TRIG: env->use_fast_trig = value != 0; return 0;
+        case AOENV_OPT_STORE_ATM_OPD: env->store_opd_atm = value != 0; return 0;
+        case 99: env->debug_ablate = value; return 0;
         default: return fail("unknown option %d", option);
     }
 }

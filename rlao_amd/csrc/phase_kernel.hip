@@ -29,7 +29,7 @@ template <typename T>
 struct KArgs {
     PhaseArgs pa;
     PhaseBuffers<T> pb;
-    int R, n_act, n_valid_act, tx;
+    int R, n_act, n_valid_act, tx, rp, ablate;
     T atm_scale;   // lambda_atm / 2 pi
     T src_scale;   // 2 pi / lambda_src
 };
@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(256) k_phase(const KArgs<T> a) {
     const size_t pix0 = (size_t)e * R * R;
     const bool separable = (a.pb.dm_opd == nullptr);
 
-    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) a.pb.wfs_max[e] = (T)0;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && a.pa.store_phase) a.pb.wfs_max[e] = (T)0;
 
     if (separable) {
         for (int i = tid; i < nA * nA; i += 256) cimg[i] = (T)0;
@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(256) k_phase(const KArgs<T> a) {
                 T atm;
                 if (a.pa.update_atm) {
                     atm = sup[i][j] * a.atm_scale;
-                    a.pb.opd_atm[pix0 + q] = atm;
+                    if (a.pa.store_atm) a.pb.opd_atm[pix0 + q] = atm;
                 } else {
                     atm = a.pb.opd_atm[pix0 + q];
                 }
@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(256) k_phase(const KArgs<T> a) {
                 }
                 const bool in = a.pb.pupil[q] != 0;
                 const T res = in ? (atm + dm) : (T)0;
-                a.pb.phase[pix0 + q] = res * a.src_scale;
+                if (a.pa.store_phase) a.pb.phase[pix0 + q] = res * a.src_scale;
                 if (in) {
                     const double da = (double)atm, dr = (double)res;
                     s_atm += da;
@@ -180,10 +180,203 @@ __global__ void __launch_bounds__(256) k_phase(const KArgs<T> a) {
         red[3][ly] = q_res;
     }
     __syncthreads();
-    if (tid < 4) {
+    if (tid < 4 && a.pa.store_phase) {
         const int tile = blockIdx.y * gridDim.x + blockIdx.x, n_tiles = gridDim.x * gridDim.y;
         a.pb.part[((size_t)e * n_tiles + tile) * 4 + tid] = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
     }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// float32 production kernel: same tile decomposition, the DM surface of the tile on the matrix cores.
+//   dm_tile[16][TX] = s1[16][nAct] . Gx^T[nAct][TX]   with v_mfma_f32_16x16x4_f32 (exact f32 fma chain)
+// Wave w owns the 16-column sub-tiles t = 2w, 2w+1; the MFMA result layout (column = lane & 15, rows
+// 4 (lane >> 4) + r) IS the lane -> pixel map of the whole kernel, so the interpolated atmosphere, the DM
+// surface and the pupil/telemetry epilogue of a pixel all live in the same lane and nothing is shuffled.
+// Per MFMA (1024 MACs) a lane reads one s1 and one Gx^T value from LDS -- 32x less LDS traffic than the
+// per-pixel dot products of the generic kernel, which were the bottleneck there.
+// ---------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(256) k_phase_mfma(const KArgs<float> a) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int R = a.R, nA = a.n_act, S = a.pa.S;
+    constexpr int TX = kTXmax, MW = TX + 4;
+    const int nAp = (nA + 3) & ~3, SS = nAp + 1;             // K padded to 4, s1 row stride odd (bank spread)
+    float* cimg = reinterpret_cast<float*>(lds_raw);         // [nA][nA]
+    float* s1 = cimg + nA * nA;                              // [16][SS]
+    float* mapt = s1 + kTY * SS;                             // [kTY + 3][MW]
+    __shared__ double red[4][4];
+
+    const int e = blockIdx.z;
+    const int x0 = blockIdx.x * TX, y0 = blockIdx.y * kTY;
+    const int txe = min(TX, R - x0), tye = min(kTY, R - y0);
+    const int tid = threadIdx.x, lx = tid & 63, ly = tid >> 6;      // ly = wave
+    const int lc = lx & 15, lq = lx >> 4;                            // MFMA lane decomposition
+    const size_t pix0 = (size_t)e * R * R;
+
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && a.pa.store_phase) a.pb.wfs_max[e] = 0.f;
+
+    for (int i = tid; i < nA * nA; i += 256) cimg[i] = 0.f;
+    for (int i = tid; i < kTY * SS; i += 256) s1[i] = 0.f;
+    __syncthreads();
+    {
+        const float* cf = a.pb.coefs + (size_t)e * a.n_valid_act;
+        for (int k = tid; k < a.n_valid_act; k += 256) cimg[a.pb.act_idx[k]] = cf[k];
+    }
+    __syncthreads();
+    // s1[y][ix] = sum_iy gy[y0 + y][iy] C[iy][ix].  The tile's rows of gy are staged in LDS first (one batch
+    // of independent loads): a per-iteration global load inside the dot product serialises 21 memory latencies.
+    if (!(a.ablate & 1)) {
+        float* gyt = mapt;                                   // [kTY][nA], the layer tile is not loaded yet
+        {
+            const float* g0 = a.pb.gy + (size_t)y0 * nA;
+            const int cnt = tye * nA;                        // contiguous rows
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = (tid + 256 * k < cnt) ? g0[tid + 256 * k] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (tid + 256 * k < cnt) gyt[tid + 256 * k] = v[k];
+            for (int i = tid + 1024; i < cnt; i += 256) gyt[i] = g0[i];
+        }
+        __syncthreads();
+        for (int i = tid; i < kTY * 32; i += 256) {
+            const int y = i >> 5;
+            for (int ix = i & 31; ix < nA; ix += 32) {
+                if (y < tye) {
+                    const float* g = gyt + y * nA;
+                    float acc = 0.f;
+#pragma unroll 8
+                    for (int iy = 0; iy < nA; ++iy) acc = fmaf(g[iy], cimg[iy * nA + ix], acc);
+                    s1[y * SS + ix] = acc;
+                }
+            }
+        }
+    }
+
+    // lane's pixels: sub-tile tt (x = 16 (2 ly + tt) + lc), rows y = 4 lq + r
+    float sup[2][4];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sup[tt][r] = 0.f;
+
+    if (a.pa.update_atm && !(a.ablate & 2)) {
+        for (int l = 0; l < a.pa.n_layer; ++l) {
+            const LayerTaps& tp = a.pa.taps[l];
+            const float* map = static_cast<const float*>(a.pa.screen[l]) + (size_t)e * S * S;
+            const int r0 = y0 + a.pa.foot + tp.dy - 1, c0 = x0 + a.pa.foot + tp.dx - 1;
+            __syncthreads();                                  // the previous layer's tile is no longer read
+            {
+                constexpr int NV = ((kTY + 3) * MW + 255) / 256;      // 10 independent loads in flight per lane
+                float v[NV];
+#pragma unroll
+                for (int k = 0; k < NV; ++k) {
+                    const int idx = tid + 256 * k;
+                    const int r = idx / MW, c = idx - r * MW;
+                    const int rr = r0 + r, cc = c0 + c;
+                    v[k] = (idx < (kTY + 3) * MW && r < tye + 3 && c < txe + 3 && rr >= 0 && rr < S && cc >= 0 && cc < S)
+                               ? map[(size_t)rr * S + cc] : 0.f;
+                }
+#pragma unroll
+                for (int k = 0; k < NV; ++k) {
+                    const int idx = tid + 256 * k;
+                    if (idx < (kTY + 3) * MW) mapt[idx] = v[k];
+                }
+            }
+            __syncthreads();
+            const float wx0 = (float)tp.wx[0], wx1 = (float)tp.wx[1], wx2 = (float)tp.wx[2], wx3 = (float)tp.wx[3];
+            const float wy0 = (float)tp.wy[0], wy1 = (float)tp.wy[1], wy2 = (float)tp.wy[2], wy3 = (float)tp.wy[3];
+            const float* mm = static_cast<const float*>(a.pa.minmax[l]) + 2 * e;
+            const float lo = mm[0], hi = mm[1], wl = (float)tp.weight;
+            const bool zero_outside = (lo > 0.f || hi < 0.f);
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const int x = 16 * (2 * ly + tt) + lc;
+                // horizontal 4-tap pass of the 7 tile rows that feed this lane's 4 output rows, then vertical
+                float h[7];
+#pragma unroll
+                for (int k = 0; k < 7; ++k) {
+                    const float* m = mapt + (4 * lq + k) * MW + x;
+                    h[k] = ((wx0 * m[0] + wx1 * m[1]) + wx2 * m[2]) + wx3 * m[3];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = ((wy0 * h[r] + wy1 * h[r + 1]) + wy2 * h[r + 2]) + wy3 * h[r + 3];
+                    if (!(zero_outside && v == 0.f)) v = v < lo ? lo : (v > hi ? hi : v);
+                    sup[tt][r] += v * wl;
+                }
+            }
+        }
+    }
+    __syncthreads();                                              // s1 complete
+
+    double s_atm = 0.0, q_atm = 0.0, s_res = 0.0, q_res = 0.0;
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const int xl = 16 * (2 * ly + tt) + lc;
+        f32x4 dmv = {0.f, 0.f, 0.f, 0.f};
+        const float* ap = s1 + lc * SS + lq;                      // A[i = lane & 15][k = lane >> 4]            (LDS)
+        const float* bp = a.pb.gxt + (size_t)lq * a.rp + x0 + xl;  // B[k = lane >> 4][j = lane & 15]  (global, L1/L2)
+        if (!(a.ablate & 4))
+        for (int kk = 0; kk < nAp; kk += 4)
+            dmv = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[kk], bp[(size_t)kk * a.rp], dmv, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int y = 4 * lq + r;
+            if (xl < txe && y < tye) {
+                const size_t q = (size_t)(y0 + y) * R + (x0 + xl);
+                float atm;
+                if (a.pa.update_atm) {
+                    atm = sup[tt][r] * a.atm_scale;
+                    if (a.pa.store_atm) a.pb.opd_atm[pix0 + q] = atm;
+                } else {
+                    atm = a.pb.opd_atm[pix0 + q];
+                }
+                const bool in = (a.ablate & 16) ? true : a.pb.pupil[q] != 0;
+                const float res = in ? (atm + dmv[r]) : 0.f;
+                if (a.pa.store_phase) a.pb.phase[pix0 + q] = res * a.src_scale;
+                if (in && !(a.ablate & 32)) {
+                    const double da = (double)atm, dr = (double)res;
+                    s_atm += da;
+                    q_atm += da * da;
+                    s_res += dr;
+                    q_res += dr * dr;
+                }
+            }
+        }
+    }
+    s_atm = wave_sum(s_atm);
+    q_atm = wave_sum(q_atm);
+    s_res = wave_sum(s_res);
+    q_res = wave_sum(q_res);
+    if (lx == 0) {
+        red[0][ly] = s_atm;
+        red[1][ly] = q_atm;
+        red[2][ly] = s_res;
+        red[3][ly] = q_res;
+    }
+    __syncthreads();
+    if (tid < 4 && a.pa.store_phase) {
+        const int tile = blockIdx.y * gridDim.x + blockIdx.x, n_tiles = gridDim.x * gridDim.y;
+        a.pb.part[((size_t)e * n_tiles + tile) * 4 + tid] = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
+    }
+}
+
+template <typename T>
+int launch_phase_mfma(const KArgs<T>&, int, hipStream_t) { return -1; }
+template <>
+int launch_phase_mfma<float>(const KArgs<float>& a, int n_env, hipStream_t st) {
+    const int nA = a.n_act, nAp = (nA + 3) & ~3, TX = kTXmax, MW = TX + 4;
+    const size_t lds = sizeof(float) * ((size_t)nA * nA + (size_t)kTY * (nAp + 1) + (size_t)(kTY + 3) * MW);
+    if (a.pb.gxt == nullptr) return -1;
+    if (lds > 160 * 1024) return -1;
+    if (lds > 64 * 1024)
+        AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_phase_mfma), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds));
+    dim3 grid(cdiv(a.R, TX), cdiv(a.R, kTY), n_env);
+    hipLaunchKernelGGL(k_phase_mfma, grid, dim3(256), lds, st, a);
+    AO_HIP(hipGetLastError());
+    return 0;
 }
 
 int phase_tiles(int R) {
@@ -193,7 +386,7 @@ int phase_tiles(int R) {
 
 template <typename T>
 int launch_phase(const PhaseArgs& pa, const PhaseBuffers<T>& pb, int n_env, int R, int n_act, int n_valid_act,
-                 double atm_wavelength, double src_wavelength, hipStream_t st) {
+                 double atm_wavelength, double src_wavelength, int use_mfma, hipStream_t st) {
     KArgs<T> a;
     a.pa = pa;
     a.pb = pb;
@@ -201,8 +394,18 @@ int launch_phase(const PhaseArgs& pa, const PhaseBuffers<T>& pb, int n_env, int 
     a.n_act = n_act;
     a.n_valid_act = n_valid_act;
     a.tx = R < kTXmax ? R : kTXmax;
+    a.rp = cdiv(R, kTXmax) * kTXmax;
+    a.ablate = use_mfma >> 8;                      // diagnostic builds only (bench of kernel sections)
     a.atm_scale = (T)(atm_wavelength / 2 / 3.14159265358979323846);
     a.src_scale = (T)(6.283185307179586476925286766559 / src_wavelength);
+    if ((use_mfma & 1) && sizeof(T) == 4 && pb.dm_opd == nullptr) {
+        // the MFMA kernel tiles with TX = 128 whatever R is (phase_tiles() is the same count for R <= 128 and
+        // for R a multiple of 128; otherwise fall through to the generic kernel)
+        if (cdiv(R, kTXmax) == cdiv(R, a.tx)) {
+            const int rc = launch_phase_mfma<T>(a, n_env, st);
+            if (rc >= 0) return rc;
+        }
+    }
     const int TX = a.tx, MW = TX + 4;
     const size_t lds = sizeof(T) * ((size_t)n_act * n_act + (size_t)kTY * n_act + (size_t)n_act * TX +
                                     (size_t)(kTY + 3) * MW + (size_t)(kTY + 3) * TX);
@@ -216,9 +419,9 @@ int launch_phase(const PhaseArgs& pa, const PhaseBuffers<T>& pb, int n_env, int 
     return 0;
 }
 
-template int launch_phase<float>(const PhaseArgs&, const PhaseBuffers<float>&, int, int, int, int, double, double,
+template int launch_phase<float>(const PhaseArgs&, const PhaseBuffers<float>&, int, int, int, int, double, double, int,
                                  hipStream_t);
 template int launch_phase<double>(const PhaseArgs&, const PhaseBuffers<double>&, int, int, int, int, double, double,
-                                  hipStream_t);
+                                  int, hipStream_t);
 
 }  // namespace ao

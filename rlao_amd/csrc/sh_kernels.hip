@@ -15,6 +15,19 @@ template <typename T> __device__ inline void sincos_t(T x, T* s, T* c);
 template <> __device__ inline void sincos_t<float>(float x, float* s, float* c) { sincosf(x, s, c); }
 template <> __device__ inline void sincos_t<double>(double x, double* s, double* c) { sincos(x, s, c); }
 
+// sin/cos through the hardware v_sin_f32 / v_cos_f32 (argument in revolutions) after a two-constant
+// Cody-Waite reduction to [-pi, pi]: |phase| reaches ~100 rad in open loop, and float32 phase * (1/2pi)
+// alone would lose ~1e-5 rad there.
+__device__ inline void sincos_fast(float x, float* s, float* c) {
+    const float n = rintf(x * 0.15915494309189535f);
+    float r = fmaf(-n, 6.28318548202514648f, x);             // 2 pi rounded to float32 ...
+    r = fmaf(-n, -1.74845553e-07f, r);                       // ... and the remainder of 2 pi
+    const float t = r * 0.15915494309189535f;
+    *s = __builtin_amdgcn_sinf(t);
+    *c = __builtin_amdgcn_cosf(t);
+}
+__device__ inline void sincos_fast(double x, double* s, double* c) { sincos(x, s, c); }
+
 __device__ inline void atomic_max_nonneg(float* addr, float v) {
     atomicMax(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
 }
@@ -141,7 +154,7 @@ __device__ constexpr double cim(int m) { return -kCos[((((m % 24) + 24) % 24) + 
 __device__ constexpr int k2(int u, int a) { return (a + LO) * (13 + 2 * u); }
 }  // namespace fast6
 
-template <typename T>
+template <typename T, bool FAST_TRIG>
 __global__ void __launch_bounds__(128, 2) k_sh_spots_p6(const T* __restrict__ phase, const ShConst<T> sc,
                                                      const uint8_t* __restrict__ valid2d, T* __restrict__ frame,
                                                      T* __restrict__ wfs_max, int R, int n_subap) {
@@ -161,23 +174,32 @@ __global__ void __launch_bounds__(128, 2) k_sh_spots_p6(const T* __restrict__ ph
 
     T mx = 0;
     for (int j0 = 0; j0 < n_subap; j0 += SPW) {
-        // ---- stage 0: strip of phase -> E0 in LDS ------------------------------------------------------
-        for (int t = lane; t < P * W; t += kWave) {
+        // ---- stage 0: strip of phase -> E0 in LDS (all loads of the lane issued before the first use) ---------
+        constexpr int NP = (P * W + kWave - 1) / kWave;                 // 12 pixels per lane
+        T phv[NP], amv[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int t = lane + k * kWave;
             const int b = t / W, c = t - b * W;
             const int col = j0 * P + c;
-            T er = 0, ei = 0;
-            if (row_ok && col < R) {
+            phv[k] = (T)0;
+            amv[k] = (T)0;
+            if (row_ok && t < P * W && col < R) {
                 const int pix = (i * P + b) * R + col;
-                const T am = sc.amp[pix];
-                if (am != (T)0) {
-                    T sn, cs;
-                    sincos_t<T>(ph[pix], &sn, &cs);
-                    er = am * cs;
-                    ei = am * sn;
-                }
+                amv[k] = sc.amp[pix];
+                phv[k] = ph[pix];
             }
-            const int jj = c / P, a = c - jj * P;
-            Ew[jj * EST + a * P + b] = {er, ei};
+        }
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int t = lane + k * kWave;
+            if (t < P * W) {
+                const int b = t / W, c = t - b * W;
+                T sn, cs;
+                if (FAST_TRIG) sincos_fast(phv[k], &sn, &cs); else sincos_t<T>(phv[k], &sn, &cs);
+                const int jj = c / P, a = c - jj * P;
+                Ew[jj * EST + a * P + b] = {amv[k] * cs, amv[k] * sn};
+            }
         }
         __syncthreads();
 
@@ -272,8 +294,12 @@ int launch_sh_spots(const T* phase, const ShConst<T>& sc, T* frame, T* wfs_max, 
     if (p == fast6::P && sc.valid2d != nullptr) {
         const size_t lds6 = 2 * (sizeof(cplx<T>) * fast6::SPW * fast6::EST + sizeof(T) * fast6::P * fast6::SPW * fast6::P);
         dim3 grid6(cdiv(n_subap, 2), n_env);
-        hipLaunchKernelGGL(k_sh_spots_p6<T>, grid6, dim3(128), lds6, st, phase, sc, sc.valid2d, frame, wfs_max, R,
-                           n_subap);
+        if (sc.fast_trig)
+            hipLaunchKernelGGL((k_sh_spots_p6<T, true>), grid6, dim3(128), lds6, st, phase, sc, sc.valid2d, frame,
+                               wfs_max, R, n_subap);
+        else
+            hipLaunchKernelGGL((k_sh_spots_p6<T, false>), grid6, dim3(128), lds6, st, phase, sc, sc.valid2d, frame,
+                               wfs_max, R, n_subap);
         AO_HIP(hipGetLastError());
         return 0;
     }
@@ -285,12 +311,14 @@ int launch_sh_spots(const T* phase, const ShConst<T>& sc, T* frame, T* wfs_max, 
     return 0;
 }
 
-// One workgroup per env; one lane per valid lenslet.
+// Centre of gravity.  grid = (ceil(nValid / 32), n_env), 256 lanes: 8 lanes per lenslet (one camera row each for
+// p <= 8; they stride over the rows otherwise), so a lane's reads are the p contiguous floats of its row and
+// all of them are in flight at once; the three partial sums are folded across the 8 lanes with DPP shuffles.
 template <typename T>
 __global__ void __launch_bounds__(256) k_sh_centroid(const T* __restrict__ frame, const T* __restrict__ wfs_max,
                                                      const ShConst<T> sc, T* __restrict__ signal, int R, int n_subap,
                                                      int n_valid, int max_group, int n_env) {
-    const int e = blockIdx.x;
+    const int e = blockIdx.y;
     const int p = R / n_subap;
     // envs of one measurement batch share the threshold maximum (ShackHartmann.py:605-660)
     const int g0 = (e / max_group) * max_group;
@@ -300,19 +328,32 @@ __global__ void __launch_bounds__(256) k_sh_centroid(const T* __restrict__ frame
     const T cut = sc.threshold * mx;
     const T* fr = frame + (size_t)e * R * R;
     T* sg = signal + (size_t)e * 2 * n_valid;
-    for (int s = threadIdx.x; s < n_valid; s += blockDim.x) {
+    const int s = blockIdx.x * 32 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
+    const bool ok = s < n_valid;
+    T norm = 0, m0 = 0, m1 = 0;
+    if (ok) {
         const int k = sc.subap_idx[s], i = k / n_subap, j = k % n_subap;
-        T norm = 0, m0 = 0, m1 = 0;
-        for (int u = 0; u < p; ++u) {
+        for (int u = sub; u < p; u += 8) {
             const T* row = fr + (size_t)(i * p + u) * R + j * p;
+            T rs = 0, rm = 0;
             for (int v = 0; v < p; ++v) {
                 T x = row[v];
                 x = x < cut ? (T)0 : x;
-                norm += x;
-                m0 += x * (T)u;
-                m1 += x * (T)v;
+                rs += x;
+                rm += x * (T)v;
             }
+            norm += rs;
+            m0 += rs * (T)u;
+            m1 += rm;
         }
+    }
+#pragma unroll
+    for (int off = 4; off > 0; off >>= 1) {
+        norm += __shfl_down(norm, off, 8);
+        m0 += __shfl_down(m0, off, 8);
+        m1 += __shfl_down(m1, off, 8);
+    }
+    if (ok && sub == 0) {
         T c0 = (T)0, c1 = (T)0;
         if (norm != (T)0) {
             c0 = m0 / norm;
@@ -326,8 +367,8 @@ __global__ void __launch_bounds__(256) k_sh_centroid(const T* __restrict__ frame
 template <typename T>
 int launch_sh_centroid(const T* frame, const T* wfs_max, const ShConst<T>& sc, T* signal, int n_env, int R,
                        int n_subap, int n_valid, int max_group, hipStream_t st) {
-    hipLaunchKernelGGL(k_sh_centroid<T>, dim3(n_env), dim3(256), 0, st, frame, wfs_max, sc, signal, R, n_subap,
-                       n_valid, max_group, n_env);
+    hipLaunchKernelGGL(k_sh_centroid<T>, dim3(cdiv(n_valid, 32), n_env), dim3(256), 0, st, frame, wfs_max, sc, signal,
+                       R, n_subap, n_valid, max_group, n_env);
     AO_HIP(hipGetLastError());
     return 0;
 }
