@@ -1,0 +1,95 @@
+"""CPU: the C-ABI library loads without a GPU and exports exactly what include/aoenv.h declares; the
+ctypes mirror of AoCfg and of the enums matches the header (checked with gcc).  No compute calls."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(REPO, "include", "aoenv.h")
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    sys.path.insert(0, REPO)
+    import __graft_entry__ as g
+    g.build()
+    from rlao_amd import _lib
+    return _lib
+
+
+def _declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(aoenv_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(built_lib):
+    lib = built_lib.load()
+    names = _declared_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} is declared in aoenv.h but not exported by libaoenv.so"
+        assert n in built_lib.EXPORTS, f"{n} has no ctypes prototype in rlao_amd/_lib.py"
+    for n in built_lib.EXPORTS:
+        assert n in names, f"{n} is bound in _lib.py but not declared in aoenv.h"
+    assert lib.aoenv_abi_version() == built_lib.ABI_VERSION
+
+
+def test_cfg_layout_and_enums_match_header(built_lib, tmp_path):
+    fields = [f[0] for f in built_lib.AoCfg._fields_]
+    prog = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void){",
+            'printf("size %zu\\n", sizeof(AoCfg));']
+    prog += [f'printf("{f} %zu\\n", offsetof(AoCfg, {f}));' for f in fields]
+    enums = ["AOENV_F32", "AOENV_F64", "AOENV_WFS_SH", "AOENV_C_PUPIL", "AOENV_C_AB", "AOENV_C_INNER_IDX",
+             "AOENV_C_OUTER_IDX", "AOENV_C_LAYER_WEIGHT", "AOENV_C_DM_GX", "AOENV_C_DM_GY", "AOENV_C_DM_MODES",
+             "AOENV_C_ACT_IDX", "AOENV_C_WFS_AMP", "AOENV_C_SH_SUBAP_IDX", "AOENV_C_SH_REF", "AOENV_C_WFS_UNITS",
+             "AOENV_C_RECON", "AOENV_B_SCREEN", "AOENV_B_OPD_ATM", "AOENV_B_COEFS", "AOENV_B_PHASE", "AOENV_B_FRAME",
+             "AOENV_B_SIGNAL", "AOENV_B_TOTAL", "AOENV_B_RESIDUAL", "AOENV_B_WFS_MAX", "AOENV_B_XI", "AOENV_K_COUNT",
+             "AOENV_OPT_FAST_WFS", "AOENV_OPT_MFMA_GEMM", "AOENV_OPT_FAST_TRIG", "AOENV_OPT_STORE_ATM_OPD"]
+    prog += [f'printf("{e} %d\\n", (int){e});' for e in enums]
+    prog += ["return 0;}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(prog))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-o", str(exe), str(src)], check=True)
+    out = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    L = built_lib
+    assert int(out["size"]) == C.sizeof(L.AoCfg)
+    for f in fields:
+        assert int(out[f]) == getattr(L.AoCfg, f).offset, f
+    mirror = dict(AOENV_F32=L.F32, AOENV_F64=L.F64, AOENV_WFS_SH=L.WFS_SH, AOENV_C_PUPIL=L.C_PUPIL, AOENV_C_AB=L.C_AB,
+                  AOENV_C_INNER_IDX=L.C_INNER_IDX, AOENV_C_OUTER_IDX=L.C_OUTER_IDX, AOENV_C_LAYER_WEIGHT=L.C_LAYER_WEIGHT,
+                  AOENV_C_DM_GX=L.C_DM_GX, AOENV_C_DM_GY=L.C_DM_GY, AOENV_C_DM_MODES=L.C_DM_MODES, AOENV_C_ACT_IDX=L.C_ACT_IDX,
+                  AOENV_C_WFS_AMP=L.C_WFS_AMP, AOENV_C_SH_SUBAP_IDX=L.C_SH_SUBAP_IDX, AOENV_C_SH_REF=L.C_SH_REF,
+                  AOENV_C_WFS_UNITS=L.C_WFS_UNITS, AOENV_C_RECON=L.C_RECON, AOENV_B_SCREEN=L.B_SCREEN,
+                  AOENV_B_OPD_ATM=L.B_OPD_ATM, AOENV_B_COEFS=L.B_COEFS, AOENV_B_PHASE=L.B_PHASE, AOENV_B_FRAME=L.B_FRAME,
+                  AOENV_B_SIGNAL=L.B_SIGNAL, AOENV_B_TOTAL=L.B_TOTAL, AOENV_B_RESIDUAL=L.B_RESIDUAL,
+                  AOENV_B_WFS_MAX=L.B_WFS_MAX, AOENV_B_XI=L.B_XI, AOENV_K_COUNT=len(L.KERNEL_NAMES),
+                  AOENV_OPT_FAST_WFS=L.OPT_FAST_WFS, AOENV_OPT_MFMA_GEMM=L.OPT_MFMA_GEMM, AOENV_OPT_FAST_TRIG=L.OPT_FAST_TRIG,
+                  AOENV_OPT_STORE_ATM_OPD=L.OPT_STORE_ATM_OPD)
+    for k, v in mirror.items():
+        assert int(out[k]) == v, k
+
+
+def test_no_gpu_means_loud_failure(built_lib):
+    """Without a GPU the env refuses to exist (there is no CPU fallback) and create() reports an error."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from rlao_amd.env import BatchedAOEnv
+    with pytest.raises(built_lib.AoEnvError):
+        BatchedAOEnv(n_envs=1)
+    lib = built_lib.load()
+    cfg = built_lib.AoCfg(abi_version=built_lib.ABI_VERSION, dtype=0, n_env=1, resolution=24, n_layer=0, layer_res=28,
+                          n_inner=208, n_outer=116, n_act=5, n_valid_act=21, dm_separable=1, wfs_type=0, n_subap=4,
+                          n_valid_subap=12, n_signal=24, cam_res=24, n_loop=8, max_group=1)
+    h = C.c_void_p()
+    assert lib.aoenv_create(C.byref(cfg), 0, C.byref(h)) != 0
+    assert len(lib.aoenv_last_error()) > 0
+    bad = built_lib.AoCfg(abi_version=999)
+    assert lib.aoenv_create(C.byref(bad), 0, C.byref(h)) != 0
+    assert b"ABI" in lib.aoenv_last_error()

@@ -1,0 +1,194 @@
+"""GPU: properties of the HIP path that the goldens do not cover -- implementation switches agree, batching is
+invariant and bitwise reproducible at the full BASELINE size, the C ABI reports errors instead of crashing,
+the single-env flavour returns the reference's types, and random (non-integrator) actions match the oracle."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+C2 = dict(diameter=8.0, nSubaperture=20, nPixelPerSubap=6, r0=0.13, L0=30.0, windSpeed=[10.0], windDirection=[72.0],
+          fractionalR0=[1.0], altitude=[0.0], nModes=50, nLoop=64)
+SMALL = dict(diameter=3.2, nSubaperture=8, nPixelPerSubap=6, r0=0.13, L0=30.0, windSpeed=[10.0], windDirection=[72.0],
+             fractionalR0=[1.0], altitude=[0.0], nModes=20, nLoop=64)
+
+
+def _run(env, steps, seed, gain=0.5):
+    import torch
+    env.generate_new_phase_screen(seed)
+    env.dm.coefs = 0
+    env.measure()
+    obs = env.reset_soft()
+    out = []
+    for i in range(steps):
+        obs, frame, rew, sr, done, info = env.step(i, gain * obs)
+        out.append((obs.clone(), frame.clone(), rew.clone(), sr.clone()))
+    torch.cuda.synchronize()
+    return out
+
+
+def test_switches_agree_small():
+    """Specialised kernels (register-resident SH, MFMA contractions, hardware trig) vs the generic ones."""
+    from rlao_amd import _lib as L
+    from rlao_amd.env import BatchedAOEnv
+    ref = None
+    for opts in [dict(), {L.OPT_FAST_WFS: 0}, {L.OPT_MFMA_GEMM: 0}, {L.OPT_FAST_TRIG: 0},
+                 {L.OPT_FAST_WFS: 0, L.OPT_MFMA_GEMM: 0, L.OPT_FAST_TRIG: 0}]:
+        env = BatchedAOEnv(n_envs=3, device=0, dtype="f32")
+        env.set_params(SMALL)
+        for k, v in opts.items():
+            L.check(env._shard.lib.aoenv_set_option(env._shard.h, k, v))
+        out = _run(env, 12, 5)
+        env.close()
+        if ref is None:
+            ref = out
+            continue
+        for (o, f, r, s), (o0, f0, r0, s0) in zip(out, ref):
+            np.testing.assert_allclose(o.cpu().numpy(), o0.cpu().numpy(), atol=2e-5)
+            np.testing.assert_allclose(f.cpu().numpy(), f0.cpu().numpy(), atol=2e-5 * float(f0.max()))
+            np.testing.assert_allclose(s.cpu().numpy(), s0.cpu().numpy(), atol=1e-5)
+            np.testing.assert_allclose(r.cpu().numpy(), r0.cpu().numpy(), rtol=1e-4, atol=2e-5)
+
+
+def test_full_size_batch_invariance_and_determinism():
+    """256 envs of the BASELINE geometry: identical seeds give bitwise identical envs wherever they sit in the
+    batch, a second run reproduces every bit (no atomics-order dependence), different seeds differ."""
+    import torch
+    from rlao_amd.env import BatchedAOEnv
+    env = BatchedAOEnv(n_envs=256, device=0, dtype="f32", env_seed_stride=0)     # every env: seed 17
+    env.set_params(C2)
+    a = _run(env, 8, 17)
+    b = _run(env, 8, 17)
+    for (o, f, r, s), (o2, f2, r2, s2) in zip(a, b):
+        assert torch.equal(o, o2) and torch.equal(f, f2) and torch.equal(r, r2) and torch.equal(s, s2)
+    o, f, r, s = a[-1]
+    assert torch.equal(o, o[:1].expand_as(o)) and torch.equal(f, f[:1].expand_as(f))
+    assert torch.equal(r, r[:1].expand_as(r)) and torch.equal(s, s[:1].expand_as(s))
+    env.env_seed_stride = 1
+    c = _run(env, 8, 17)
+    assert torch.equal(c[-1][0][0], o[0])                       # env 0 still has seed 17
+    assert not torch.equal(c[-1][0][1], o[1])                   # env 1 now has seed 18
+    assert float(c[-1][3].std()) > 0
+    env.close()
+
+
+def test_run_integrator_equals_stepping():
+    import torch
+    from rlao_amd.env import BatchedAOEnv
+    env = BatchedAOEnv(n_envs=4, device=0, dtype="f32")
+    env.set_params(SMALL, gainCL=0.4)
+    a = _run(env, 10, 3, gain=0.4)
+    env.generate_new_phase_screen(3)
+    env.dm.coefs = 0
+    env.measure()
+    env.reset_soft()
+    obs, rew, sr = env.run_integrator(0, 10)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(obs.cpu().numpy(), a[-1][0].cpu().numpy(), atol=1e-6)
+    np.testing.assert_allclose(sr.cpu().numpy(), a[-1][3].cpu().numpy(), atol=1e-6)
+    np.testing.assert_allclose(env.total[:10], env.total[:10])
+    env.close()
+
+
+def test_random_actions_match_oracle_c2():
+    """Three envs of the BASELINE geometry, arbitrary bounded actions (not the integrator), against the oracle."""
+    import torch
+    from oracle import ao_oracle as O
+    from rlao_amd.env import BatchedAOEnv
+    env = BatchedAOEnv(n_envs=3, device=0, dtype="f32", env_seed_stride=100)
+    env.set_params(C2)
+    env.generate_new_phase_screen(23)
+    env.dm.coefs = 0
+    env.measure()
+    obs = env.reset_soft().cpu().numpy()
+    rs = np.random.RandomState(9)
+    orcs = []
+    for k in range(3):
+        o = O.OracleEnv(resolution=120, diameter=8.0, n_subap=20, r0=0.13, L0=30.0, windSpeed=[10.0], windDirection=[72.0],
+                        fractionalR0=[1.0], altitude=[0.0], m2c=env.M2C_CL, n_modes=50)
+        o.new_episode(23 + 100 * k)
+        np.testing.assert_allclose(obs[k], o.reset_soft(), atol=3e-5)
+        orcs.append(o)
+    for i in range(6):
+        act = (0.4 * obs + 0.05 * rs.randn(*obs.shape)).astype(np.float32)
+        act *= env.dm_mask[None]
+        got, frame, rew, sr, _, _ = env.step(i, torch.as_tensor(act))
+        obs = got.cpu().numpy()
+        for k, o in enumerate(orcs):
+            oo, of, orw, osr, _, _ = o.step(i, act[k])
+            np.testing.assert_allclose(obs[k], oo, atol=3e-5)
+            np.testing.assert_allclose(float(rew[k]), orw, rtol=1e-4)
+            np.testing.assert_allclose(float(sr[k]), osr, atol=1e-5)
+            np.testing.assert_allclose(frame[k].cpu().numpy(), of, atol=5e-5 * of.max())
+    env.close()
+
+
+def test_single_env_flavour_returns_reference_types(golden_dir):
+    """OOPAO(): numpy / float returns so that drl4ao's own TorchWrapper and run() loops work unchanged."""
+    import torch
+    from rlao_amd.env import OOPAO
+    from rlao_amd.wrappers import TorchWrapper
+    g = np.load(os.path.join(golden_dir, "small_sh.npz"))
+    env = OOPAO(device=0, dtype="f64")
+    env.set_params_file("Conf.parameterFile_oopao_parser", "AO_OOPAO")
+    env.set_params(SMALL, m2c=g["m2c"])
+    env.atm.generateNewPhaseScreen(17)
+    env.dm.coefs = 0
+    env.tel * env.dm * env.wfs
+    obs = env.reset_soft()
+    assert isinstance(obs, np.ndarray) and obs.shape == (9, 9) and obs.dtype == np.float64
+    np.testing.assert_allclose(obs, g["s17_obs0"], atol=1e-6)
+    nxt, wfsf, reward, strehl, done, info = env.step(0, g["s17_actions"][0])
+    assert isinstance(nxt, np.ndarray) and isinstance(wfsf, np.ndarray) and isinstance(reward, float)
+    assert isinstance(strehl, float) and done is False and set(info) == {"strehl"}
+    np.testing.assert_allclose(nxt, g["s17_obs"][0], atol=1e-6)
+    np.testing.assert_allclose(reward, g["s17_reward"][0], rtol=1e-6)
+    assert env.wfs.signal.shape == (env.nSignal,) and env.wfs.cam.frame.shape == (48, 48)
+    assert env.dm.coefs.shape == (env.nValidAct,)
+    np.testing.assert_allclose(env.total[0], g["s17_total"][0], atol=1e-4)
+    mean, std = env.calculate_strehl_AVG()
+    assert abs(mean - g["s17_strehl"][0]) < 1e-7 and std == 0.0 and env.SR == []
+    # wrappers + helpers
+    w = TorchWrapper(env)
+    o2, _, r2, s2, d2, info2 = w.step(1, torch.as_tensor(g["s17_actions"][1]))
+    assert o2.dtype == torch.float32 and o2.device.type == "cpu" and info2[0][0] == "strehl"
+    np.testing.assert_allclose(o2.numpy(), g["s17_obs"][1], atol=1e-5)
+    img = env.vec_to_img(np.arange(env.nValidAct, dtype=float))
+    np.testing.assert_array_equal(env.img_to_vec(img), np.arange(env.nValidAct))
+    assert env.img_to_vec(torch.zeros(2, 5, 9, 9)).shape == (2, 5, env.nValidAct)
+    np.random.seed(5)
+    n1 = env.sample_noise(0.2, use_torch=True)
+    np.random.seed(5)
+    want = env.F @ (0.2 * np.random.normal(0, 1, size=(env.nValidAct,)))
+    np.testing.assert_allclose(env.img_to_vec(n1).cpu().numpy(), want, rtol=1e-5, atol=1e-7)
+    env.atm.windSpeed = [20.0]
+    env.atm.r0 = 0.1
+    env.step(2, np.zeros((9, 9)))
+    env.close()
+
+
+def test_c_abi_reports_errors():
+    from rlao_amd import _lib as L
+    from rlao_amd.env import BatchedAOEnv
+    lib = L.load()
+    env = BatchedAOEnv(n_envs=2, device=0, dtype="f32")
+    env.set_params(SMALL)
+    h = env._shard.h
+    assert lib.aoenv_step(h, 10 ** 6, C.c_void_p(env._obs.data_ptr()), C.c_void_p(env._obs.data_ptr()), None, None, None, None) != 0
+    assert b"frame index" in lib.aoenv_last_error()
+    assert lib.aoenv_step(h, 0, None, None, None, None, None, None) != 0
+    bad = np.zeros(3)
+    assert lib.aoenv_upload(h, L.C_RECON, bad.ctypes.data_as(C.c_void_p), bad.nbytes) != 0
+    assert b"expected" in lib.aoenv_last_error()
+    assert lib.aoenv_upload(h, 999, bad.ctypes.data_as(C.c_void_p), bad.nbytes) != 0
+    assert lib.aoenv_set_option(h, 12345, 1) != 0
+    assert lib.aoenv_download(h, L.B_SIGNAL, bad.ctypes.data_as(C.c_void_p), 8, None) != 0
+    idx = np.full(env._atm_tables.n_inner, 10 ** 6, dtype=np.int32)
+    assert lib.aoenv_upload(h, L.C_INNER_IDX, idx.ctypes.data_as(C.c_void_p), idx.nbytes) != 0
+    with pytest.raises(ValueError):
+        env.step(0, np.zeros((5, 5)))
+    # the env still works after the rejected calls
+    env.step(0, np.zeros((2, 9, 9), dtype=np.float32))
+    env.close()

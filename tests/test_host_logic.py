@@ -1,0 +1,110 @@
+"""CPU: host-side logic that needs no GPU -- parameter parsing, sharding, wrappers, the warp spec of the oracle."""
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ao_oracle as O
+from rlao_amd import calib
+from rlao_amd import dist as aodist
+from rlao_amd.wrappers import TimeDelayEnv, TorchWrapper
+
+
+def test_params_accept_both_reference_spellings():
+    a = calib.params_from_args(SimpleNamespace(r0=0.1, L0=25, fractionnalR0=[0.7, 0.3], windSpeed=[5, 6],
+                                               windDirection=[0, 90], altitude=[0, 0], nLoop=100, gainCL=0.3, modulation=0))
+    b = calib.params_from_args(dict(r0=0.1, L0=25, fractionalR0=[0.7, 0.3], windSpeed=[5, 6], windDirection=[0, 90],
+                                    altitude=[0, 0], nLoop=100, gainCL=0.3))
+    assert a.fractionalR0 == b.fractionalR0 == [0.7, 0.3] and a.nLayer == 2
+    assert a.resolution == 120 and a.nActuator == 21 and a.extra == {"modulation": 0}
+    with pytest.raises(ValueError):
+        calib.params_from_args(dict(fractionalR0=[1.0], windSpeed=[1.0, 2.0]))
+
+
+def test_shard_bounds_cover_everything_once():
+    for n, w in [(256, 1), (256, 8), (4096, 8), (10, 4), (3, 8)]:
+        seen = []
+        for r in range(w):
+            lo, hi = aodist.shard_bounds(n, r, w)
+            assert 0 <= lo <= hi <= n
+            seen += list(range(lo, hi))
+        assert seen == list(range(n))
+    with pytest.raises(ValueError):
+        aodist.shard_bounds(8, 8, 8)
+
+
+class _FakeEnv:
+    """NumPy env with the reference's return convention (for the wrappers)."""
+    output = "numpy"
+    nActuator = 3
+    n_envs = 1
+
+    def __init__(self):
+        self.seen = []
+
+    def reset_soft(self):
+        return np.ones((3, 3))
+
+    def step(self, i, action):
+        self.seen.append(np.array(action, dtype=float))
+        return np.full((3, 3), float(i)), np.zeros((2, 2)), -1.5, 0.25, False, {"strehl": 0.25}
+
+
+def test_torch_wrapper_reference_convention():
+    env = TorchWrapper(_FakeEnv())
+    obs = env.reset_soft()
+    assert obs.dtype == torch.float32 and obs.shape == (3, 3)
+    nxt, wfsf, rew, sr, done, info = env.step(4, torch.full((3, 3), 2.0))
+    assert nxt.dtype == torch.float32 and float(nxt[0, 0]) == 4.0 and rew == -1.5 and sr == 0.25 and done is False
+    assert info[0][0] == "strehl" and info[0][1].dtype == torch.float32
+    assert env.nActuator == 3                                   # attribute forwarding
+
+
+def test_time_delay_env_is_a_fifo():
+    inner = _FakeEnv()
+    env = TimeDelayEnv(inner, 2)
+    env.reset_soft()
+    for i in range(4):
+        env.step(i, np.full((3, 3), float(i + 1)))
+    got = [float(a[0, 0]) for a in inner.seen]
+    assert got == [0.0, 0.0, 1.0, 2.0]
+
+
+def test_warp_spec_properties():
+    """Frozen spec of skimage.warp(order=3) for translations (the one stage the reference cannot pin)."""
+    rs = np.random.RandomState(0)
+    img = rs.randn(20, 23)
+    np.testing.assert_array_equal(O.warp_translate(img, 0.0, 0.0), img)
+    for tx, ty in [(1, 0), (0, -1), (-1, 1)]:                    # integer shifts move pixels exactly, zero fill
+        out = O.warp_translate(img, tx, ty)
+        ref = np.zeros_like(img)
+        ys, xs = np.mgrid[0:20, 0:23]
+        sy, sx = ys - ty, xs - tx
+        ok = (sy >= 0) & (sy < 20) & (sx >= 0) & (sx < 23)
+        ref[ok] = img[sy[ok], sx[ok]]
+        np.testing.assert_array_equal(out, np.clip(ref, img.min(), img.max()))
+    # Catmull-Rom reproduces quadratics exactly away from the border
+    yy, xx = np.mgrid[0:30, 0:30].astype(float)
+    quad = 0.3 * xx ** 2 - 0.2 * xx * yy + 0.1 * yy ** 2 + xx - 2 * yy + 5
+    out = O.warp_translate(quad, 0.37, -0.61)
+    want = 0.3 * (xx - 0.37) ** 2 - 0.2 * (xx - 0.37) * (yy + 0.61) + 0.1 * (yy + 0.61) ** 2 + (xx - 0.37) - 2 * (yy + 0.61) + 5
+    want = np.clip(want, quad.min(), quad.max())                 # clip=True: the minimum of the bowl is cut
+    np.testing.assert_allclose(out[3:-3, 3:-3], want[3:-3, 3:-3], atol=1e-10)
+    # output is clipped to the input range
+    spike = np.zeros((12, 12))
+    spike[6, 6] = 1.0
+    out = O.warp_translate(spike, 0.5, 0.5)
+    assert out.min() >= 0.0 and out.max() <= 1.0
+
+
+def test_catmull_rom_weights_match_the_nested_form():
+    """The HIP kernels use tap weights; the oracle uses skimage's nested cubic.  Same polynomial."""
+    for x in [0.0, 0.1, 0.5, 0.999]:
+        w = np.array([0.5 * (-x ** 3 + 2 * x ** 2 - x), 0.5 * (3 * x ** 3 - 5 * x ** 2 + 2),
+                      0.5 * (-3 * x ** 3 + 4 * x ** 2 + x), 0.5 * (x ** 3 - x ** 2)])
+        f = np.array([0.3, -1.2, 2.5, 0.7])
+        assert abs(w @ f - O._cubic(x, *f)) < 1e-14
+        assert abs(w.sum() - 1) < 1e-14
