@@ -28,6 +28,19 @@ GEOMETRY = dict(diameter=8.0, nSubaperture=20, nPixelPerSubap=6, r0=0.13, L0=30.
                 windDirection=[72.0], fractionalR0=[1.0], altitude=[0.0], magnitude=8.0, opticalBand="I",
                 mechanicalCoupling=0.35, nModes=50, gainCL=0.5, leak=0.99)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+PMC_TRAFFIC = os.path.join(REPO, "profiles", "r01_b_pmc_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+
+
+def measured_traffic(kernel, n_envs):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (same command, same n_envs), else None."""
+    try:
+        with open(PMC_TRAFFIC) as f:
+            d = json.load(f)
+        if d.get("n_envs") == n_envs:
+            return d["kernels"][kernel]["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
 
 
 def algorithmic_bytes(env):
@@ -150,7 +163,7 @@ def main():
                    "n_signal": env.nSignal, "layers": env.param.nLayer, "controller": "leaky integrator, gain 0.5",
                    "noise": "off", "parallelism": f"env-shards x{world}, all-gather of episode returns"},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(dom, n_local),
                      "algorithmic_bytes_per_launch": kbytes[dom] * n_local, "avg_launch_us": per_kernel[dom]["avg_us"]},
         "step_roofline": {"algorithmic_bytes_per_env_step": step_bytes,
                           "achieved_GBs": step_bytes * n_local / (dt / K) / 1e9,
