@@ -461,6 +461,152 @@ class OracleSH:
 
 
 # --------------------------------------------------------------------------------------
+# Pyramid WFS (single wavefront)                                   (OOPAO/Pyramid.py)
+# --------------------------------------------------------------------------------------
+class OraclePyramid:
+    """Fourier-filtering pyramid sensor: zero-padded FFT -> 4-facet phase mask -> inverse FFT -> |.|^2, summed over
+    the modulation points, binned to the camera, quadrant slopes maps.  Quirks kept: the mask is stored as
+    complex64 (:323) and the modulation tip/tilt buffer as float32 (:964-970)."""
+
+    def __init__(self, n_subap, resolution, pupil, wavelength, flux_map, modulation=0.0, light_ratio=0.1,
+                 n_pix_separation=4, n_pix_edge=2, psf_centering=True, post_processing="slopesMaps_incidence_flux",
+                 calib_modulation=50):
+        self.nSubap, self.R, self.pupil = n_subap, resolution, pupil
+        self.pupil_f = pupil.astype(float)
+        self.flux_map = flux_map
+        self.psfCentering = psf_centering
+        self.postProcessing = post_processing
+        self.n_pix_separation, self.n_pix_edge = n_pix_separation, n_pix_edge
+        R = resolution
+        self.nRes = int((n_subap * 2 + n_pix_separation + n_pix_edge * 2) * R / n_subap)          # :251
+        self.zeroPaddingFactor = self.nRes / R
+        self.cam_res = round(n_subap * self.zeroPaddingFactor)                                      # :255
+        self.center = self.nRes // 2
+        self.calibModulation = R / 2 - 1 if calib_modulation >= R / 2 else calib_modulation        # :259-262
+        tip, tilt = np.meshgrid(np.linspace(-np.pi, np.pi, R), np.linspace(-np.pi, np.pi, R))       # :288-290
+        self.Tilt = tilt * self.pupil_f
+        self.Tip = tip * self.pupil_f
+        n = self.nRes
+        xx, yy = np.meshgrid(np.linspace(0, n - 1, n), np.linspace(0, n - 1, n))
+        self.phasor = np.exp(-(1j * np.pi * (n + 1) / n) * (xx + yy))                               # :293-294
+        self.m = self.phase_mask()
+        self.mask = np.complex64(np.exp(1j * self.m))                                               # :323
+        self.referenceSignal_2D = 0
+        self.slopesUnits = 1
+        self.isInitialized = False
+        # valid-pixel selection at the (large) calibration modulation, then reference slopes at the user modulation
+        self.set_modulation(self.calibModulation)
+        self.measure(np.zeros((R, R)), process=False)                                               # :408-415
+        I1, I2, I3, I4 = (self.grab_quadrant(k) for k in (1, 2, 3, 4))
+        self.I4Q = I1 + I2 + I3 + I4
+        self.validI4Q = self.I4Q >= light_ratio * self.I4Q.max()                                     # :426-430
+        self.validSignal = np.concatenate((self.validI4Q, self.validI4Q))
+        self.nSignal = int(np.sum(self.validSignal))
+        self.isInitialized = True
+        self.set_modulation(modulation)
+        # wfs_calibration :454-466: OPD = pupil (1 m of piston inside the pupil)
+        self.measure(self.pupil_f * TWO_PI / wavelength, process=False)
+        self.referenceSignal_2D, _ = self.signal_processing()
+        self.measure(np.zeros((R, R)))                                                              # :313-314
+
+    def phase_mask(self):
+        """get_phase_mask :368-405 with sx = sy = 0."""
+        n_tot = self.nRes
+        norma = (self.nSubap + self.n_pix_separation) * (self.R / self.nSubap)
+        m = np.zeros([n_tot, n_tot])
+        h = n_tot // 2
+        if self.psfCentering:
+            lim = np.pi / 4
+            d_pix = np.pi / 4 / h
+            lim = lim - d_pix
+            Tip, Tilt = np.meshgrid(np.linspace(-lim, lim, h), np.linspace(-lim, lim, h))
+            m[:h, :h] = Tip * norma + Tilt * norma
+            m[:h, -h:] = -Tip * norma + Tilt * norma
+            m[-h:, -h:] = -Tip * norma + -Tilt * norma
+            m[-h:, :h] = Tip * norma + -Tilt * norma
+        else:
+            d_pix = (np.pi / 4) / (n_tot / 2)
+            lim_p = np.pi / 4
+            lim_m = np.pi / 4 - 2 * d_pix
+            Tip_1, Tilt_1 = np.meshgrid(np.linspace(-lim_p, lim_p, h + 1), np.linspace(-lim_p, lim_p, h + 1))
+            Tip_2, Tilt_2 = np.meshgrid(np.linspace(-lim_p, lim_p, h + 1), np.linspace(-lim_m, lim_m, h - 1))
+            Tip_3, Tilt_3 = np.meshgrid(np.linspace(-lim_m, lim_m, h - 1), np.linspace(-lim_m, lim_m, h - 1))
+            Tip_4, Tilt_4 = np.meshgrid(np.linspace(-lim_m, lim_m, h - 1), np.linspace(-lim_p, lim_p, h + 1))
+            m[:h + 1, :h + 1] = Tip_1 * norma + Tilt_1 * norma
+            m[:h + 1, -h + 1:] = -Tip_4 * norma + Tilt_4 * norma
+            m[-h + 1:, -h + 1:] = -Tip_3 * norma + -Tilt_3 * norma
+            m[-h + 1:, :h + 1] = Tip_2 * norma + -Tilt_2 * norma
+        return -m
+
+    def set_modulation(self, val):
+        """modulation setter :941-976."""
+        self.modulation = val
+        if val != 0:
+            perimeter = np.pi * 2 * val
+            self.nTheta = 4 * int(0 + np.ceil(perimeter / 4))
+            theta = np.linspace(0, 2 * np.pi, self.nTheta, endpoint=False)
+            buf = np.zeros([self.nTheta, self.R, self.R]).astype(np.float32)
+            for i in range(self.nTheta):
+                buf[i] = (val * np.cos(theta[i]) * self.Tip + val * np.sin(theta[i]) * self.Tilt) * self.pupil_f
+            self.tt_buffer = buf
+        else:
+            self.nTheta = 1
+            self.tt_buffer = None
+
+    def transform(self, phase):
+        """pyramid_transform :469-504."""
+        n, R, c = self.nRes, self.R, self.center
+        support = np.zeros((n, n), dtype=complex)
+        support[c - R // 2:c + R // 2, c - R // 2:c + R // 2] = self.maskAmplitude * np.exp(1j * phase)
+        if self.psfCentering:
+            ft = np.fft.fft2(support * self.phasor)
+        else:
+            ft = np.fft.fftshift(np.fft.fft2(support))
+        return np.abs(np.fft.ifft2(ft * self.mask)) ** 2
+
+    def measure(self, phase, process=True):
+        self.maskAmplitude = np.sqrt(self.flux_map / self.nTheta) * self.pupil_f                    # :520
+        if self.modulation == 0:
+            frame = self.transform(phase)
+        else:
+            frame = np.zeros((self.nRes, self.nRes))
+            for i in range(self.nTheta):
+                frame = frame + self.transform(phase + self.tt_buffer[i])
+        self.pyramidFrame = frame
+        b = self.nRes // self.cam_res
+        self.frame = frame.reshape(self.cam_res, b, self.cam_res, b).sum(-1).sum(1)                 # set_binning, :999
+        if process and self.isInitialized:
+            self.signal_2D, self.signal = self.signal_processing()
+            return self.signal
+
+    def grab_quadrant(self, n):
+        """grabQuadrant :774-790 (binning 1, no rooftop)."""
+        ne = int(np.round((self.n_pix_separation / self.nSubap) * self.R / (self.R / self.nSubap) / 2))
+        c = int(np.round(self.cam_res / 2))
+        p = int(np.ceil(self.nSubap))
+        f = self.frame
+        if n == 3:
+            return f[ne + c:ne + c + p, ne + c:ne + c + p]
+        if n == 4:
+            return f[ne + c:ne + c + p, -ne + c - p:-ne + c]
+        if n == 1:
+            return f[-ne + c - p:-ne + c, -ne + c - p:-ne + c]
+        return f[-ne + c - p:-ne + c, ne + c:ne + c + p]
+
+    def signal_processing(self):
+        """signalProcessing :682-725."""
+        I1, I2, I3, I4 = (self.grab_quadrant(k) * self.validI4Q for k in (1, 2, 3, 4))
+        if self.postProcessing == "slopesMaps":
+            norma = np.mean((I1 + I2 + I3 + I4)[self.validI4Q])
+        else:
+            norma = np.float64(self.frame.mean())
+        Sx = I1 - I2 + I4 - I3
+        Sy = I1 - I4 + I2 - I3
+        maps = (np.concatenate((Sx, Sy)) / norma - self.referenceSignal_2D) * self.slopesUnits
+        return maps, maps[np.where(self.validSignal == 1)]
+
+
+# --------------------------------------------------------------------------------------
 # Zernike basis (Noll), as the reference builds it          (OOPAO/Zernike.py:26-66)
 # aotools 1.0.6 (third party, absent) supplies zernIndex / zernikeRadialFunc: restated here.
 # --------------------------------------------------------------------------------------
@@ -526,8 +672,9 @@ def calibration_vault_M(D: np.ndarray) -> np.ndarray:
 class OracleEnv:
     def __init__(self, resolution=120, diameter=8.0, n_subap=20, dt=1 / 500, band="I", magnitude=8.0,
                  r0=0.13, L0=30.0, windSpeed=(10.0,), windDirection=(72.0,), fractionalR0=(1.0,),
-                 altitude=(0.0,), mech_coupling=0.35, m2c=None, n_modes=50, light_ratio=0.5,
-                 threshold_cog=0.01, nLoop=10000, leak=0.99, gainCL=0.5, n_meas=6):
+                 altitude=(0.0,), mech_coupling=0.35, m2c=None, n_modes=50, light_ratio=None,
+                 threshold_cog=0.01, nLoop=10000, leak=0.99, gainCL=0.5, n_meas=6, wfs_type="sh", modulation=0.0,
+                 psf_centering=True):
         self.R, self.D, self.dt = resolution, diameter, dt
         self.leak, self.gainCL = leak, gainCL
         self.pupil = make_pupil(resolution)
@@ -542,8 +689,14 @@ class OracleEnv:
         self.dm_mask = dm["validAct"].reshape(self.nActuator, self.nActuator)
         self.xvalid, self.yvalid = np.nonzero(self.dm_mask)
         self.nValidAct = int(dm["validAct"].sum())
-        self.wfs = OracleSH(n_subap, resolution, diameter, self.pupil, self.wavelength, self.flux_map,
-                            light_ratio, threshold_cog)
+        self.wfs_type = wfs_type
+        if wfs_type == "sh":
+            self.wfs = OracleSH(n_subap, resolution, diameter, self.pupil, self.wavelength, self.flux_map,
+                                0.5 if light_ratio is None else light_ratio, threshold_cog)
+        else:                                                    # MAIN/OOPAOEnv/OOPAOEnv.py:239-246
+            self.wfs = OraclePyramid(n_subap, resolution, self.pupil, self.wavelength, self.flux_map,
+                                     modulation=modulation, light_ratio=0.1 if light_ratio is None else light_ratio,
+                                     psf_centering=psf_centering)
         if m2c is None:
             Z = zernike_modes(self.pupil, diameter, n_modes)
             m2c = np.linalg.pinv(self.dm_modes[self.pupil.reshape(-1)]) @ Z
@@ -578,6 +731,12 @@ class OracleEnv:
         that share the centroid-threshold maximum (multi-wavefront branch, ShackHartmann.py:605-672)."""
         nA = self.nValidAct
         D = np.zeros((self.wfs.nSignal, nA))
+        if self.wfs_type != "sh":                                # Pyramid: the batched measurements are independent
+            for a in range(nA):
+                cf = np.zeros(nA)
+                cf[a] = stroke
+                D[:, a] = self.wfs.measure(self.dm_opd(cf) * self.pupil * TWO_PI / self.wavelength) / stroke
+            return D
         k = 0
         n_cycle = int(np.ceil(nA / n_meas))
         n_extra = nA % n_meas

@@ -42,6 +42,15 @@ CASES = {
                      n_modes=20, steps=50, seeds=[0, 17], gain=0.5, full_every=10),
     "c2_sh": dict(R=120, nsub=20, D=8.0, r0=0.13, L0=30.0, ws=[10.0], wd=[72.0], frac=[1.0], alt=[0.0],
                   n_modes=50, steps=20, seeds=[17], gain=0.5, full_every=10, m2c_file=True),
+    # Pyramid WFS (MAIN/OOPAOEnv/OOPAOEnv.py:239-246): unmodulated / centred mask, and modulated / one-pixel mask
+    "tiny_pyr": dict(R=24, nsub=4, D=1.6, r0=0.13, L0=30.0, ws=[10.0], wd=[72.0], frac=[1.0], alt=[0.0],
+                     n_modes=8, steps=30, seeds=[0, 17], gain=0.5, full_every=1, wfs="pyr", modulation=0, centering=True),
+    "tiny_pyr_mod": dict(R=24, nsub=4, D=1.6, r0=0.13, L0=30.0, ws=[10.0], wd=[72.0], frac=[1.0], alt=[0.0],
+                         n_modes=8, steps=20, seeds=[17], gain=0.5, full_every=1, wfs="pyr", modulation=2, centering=False),
+    # the reference's own Papyrus configuration (MAIN/Conf/papyrus_config.yaml + parameterFile_oopao_parser.py)
+    "papyrus_pyr": dict(R=120, nsub=20, D=1.52, r0=0.25, L0=10.0, ws=[20.0], wd=[72.0], frac=[1.0], alt=[0.0],
+                        n_modes=50, steps=12, seeds=[0], gain=0.5, full_every=6, m2c_file=True, wfs="pyr", modulation=0,
+                        centering=True),
 }
 
 
@@ -61,8 +70,13 @@ def build(ref, c):
                                   pitch=tel.D / nAct)
         tel.isPaired = False
         tel.resetOPD()
-        wfs = ref.ShackHartmann(telescope=tel, nSubap=c["nsub"], lightRatio=0.5, is_geometric=False,
-                                shannon_sampling=True)
+        if c.get("wfs", "sh") == "sh":
+            wfs = ref.ShackHartmann(telescope=tel, nSubap=c["nsub"], lightRatio=0.5, is_geometric=False,
+                                    shannon_sampling=True)
+        else:
+            wfs = ref.Pyramid(nSubap=c["nsub"], telescope=tel, lightRatio=0.1, modulation=c["modulation"], binning=1,
+                              n_pix_separation=4, n_pix_edge=2, postProcessing="slopesMaps_incidence_flux",
+                              psfCentering=c["centering"])
         tel * wfs
         if c.get("m2c_file"):
             m2c = np.load(MANUAL_M2C)[:, :c["n_modes"]]                    # OOPAOEnv.py:260
@@ -158,10 +172,16 @@ def make_case(ref, name):
         cfg_ws=np.array(c["ws"]), cfg_wd=np.array(c["wd"]), cfg_frac=np.array(c["frac"]), cfg_alt=np.array(c["alt"]),
         cfg_gain=c["gain"], cfg_n_modes=c["n_modes"], cfg_seeds=np.array(c["seeds"]),
         pupil=tel.pupil.astype(bool), wavelength=env["ngs"].wavelength, nPhoton=env["ngs"].nPhoton,
-        validAct=np.asarray(dm.validAct, bool), valid_subap=np.asarray(wfs.valid_subapertures, bool),
-        reference_slopes_maps=wfs.reference_slopes_maps, slopes_units=wfs.slopes_units,
+        validAct=np.asarray(dm.validAct, bool),
         m2c=env["m2c"], imat=env["D"], recon=env["recon"], F=env["F"],
         xvalid=env["xvalid"], yvalid=env["yvalid"])
+    if c.get("wfs", "sh") == "sh":
+        consts.update(valid_subap=np.asarray(wfs.valid_subapertures, bool),
+                      reference_slopes_maps=wfs.reference_slopes_maps, slopes_units=wfs.slopes_units)
+    else:
+        consts.update(cfg_wfs="pyr", cfg_modulation=c["modulation"], cfg_centering=c["centering"],
+                      validI4Q=np.asarray(wfs.validI4Q, bool), referenceSignal_2D=wfs.referenceSignal_2D,
+                      pyr_m=wfs.m if c["R"] <= 48 else wfs.m[::7, ::5], nTheta=wfs.nTheta)
     if c["R"] <= 48:
         consts.update(A=L1.A, B=L1.B, modes=dm.modes)
     else:

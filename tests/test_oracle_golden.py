@@ -11,14 +11,17 @@ import pytest
 
 from oracle import ao_oracle as O
 
-CASES = ["tiny_sh", "tiny_fastwind", "tiny_3layer", "small_sh", "c2_sh"]
+CASES = ["tiny_sh", "tiny_fastwind", "tiny_3layer", "small_sh", "c2_sh", "tiny_pyr", "tiny_pyr_mod", "papyrus_pyr"]
 
 
 def _env_from_golden(g):
+    kw = {}
+    if "cfg_wfs" in g:
+        kw = dict(wfs_type="pyramid", modulation=float(g["cfg_modulation"]), psf_centering=bool(g["cfg_centering"]))
     return O.OracleEnv(resolution=int(g["cfg_R"]), diameter=float(g["cfg_D"]), n_subap=int(g["cfg_nsub"]),
                        r0=float(g["cfg_r0"]), L0=float(g["cfg_L0"]), windSpeed=list(g["cfg_ws"]),
                        windDirection=list(g["cfg_wd"]), fractionalR0=list(g["cfg_frac"]),
-                       altitude=list(g["cfg_alt"]), m2c=g["m2c"], n_modes=int(g["cfg_n_modes"]))
+                       altitude=list(g["cfg_alt"]), m2c=g["m2c"], n_modes=int(g["cfg_n_modes"]), **kw)
 
 
 @pytest.fixture(scope="module", params=CASES)
@@ -32,10 +35,16 @@ def test_constants(case):
     assert np.array_equal(env.pupil, g["pupil"])
     assert env.wavelength == float(g["wavelength"]) and env.nPhoton == float(g["nPhoton"])
     assert np.array_equal(env.dm_mask.reshape(-1), g["validAct"])
-    assert np.array_equal(env.wfs.valid_2d, g["valid_subap"])
     assert np.array_equal(env.xvalid, g["xvalid"]) and np.array_equal(env.yvalid, g["yvalid"])
-    np.testing.assert_allclose(env.wfs.reference_slopes_maps, g["reference_slopes_maps"], atol=1e-13)
-    np.testing.assert_allclose(env.wfs.slopes_units, float(g["slopes_units"]), rtol=1e-11)
+    if "cfg_wfs" in g:
+        assert np.array_equal(env.wfs.validI4Q, g["validI4Q"]) and env.wfs.nTheta == int(g["nTheta"])
+        np.testing.assert_allclose(env.wfs.referenceSignal_2D, g["referenceSignal_2D"], atol=1e-13)
+        m = env.wfs.m if env.R <= 48 else env.wfs.m[::7, ::5]
+        np.testing.assert_allclose(m, g["pyr_m"], atol=1e-13)
+    else:
+        assert np.array_equal(env.wfs.valid_2d, g["valid_subap"])
+        np.testing.assert_allclose(env.wfs.reference_slopes_maps, g["reference_slopes_maps"], atol=1e-13)
+        np.testing.assert_allclose(env.wfs.slopes_units, float(g["slopes_units"]), rtol=1e-11)
     lay = env.atm.layers[0]
     if "A" in g:
         np.testing.assert_allclose(lay.A, g["A"], atol=1e-12)
