@@ -109,7 +109,7 @@ def main():
 
     env = BatchedAOEnv(n_envs=n_local, device=local, dtype=args.dtype, return_frame=True,
                        env_index_offset=rank * n_local)
-    env.set_params(dict(GEOMETRY, nLoop=2 * (K + W) + 16))
+    env.set_params(dict(GEOMETRY, nLoop=2 * (K + W) + 16), wfs_type="shackhartmann")
     env.generate_new_phase_screen(17)              # env e of the job uses seed 17 + e
     env.dm.coefs = 0
     env.measure()

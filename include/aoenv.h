@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define AOENV_ABI_VERSION 1
+#define AOENV_ABI_VERSION 2
 
 enum { AOENV_F32 = 0, AOENV_F64 = 1 };
 enum { AOENV_WFS_SH = 0, AOENV_WFS_PYRAMID = 1 };
@@ -59,7 +59,11 @@ typedef struct AoCfg {
                                 maximum (1 in the loop; nMeasurements when emulating the batched
                                 interaction-matrix measurement, OOPAO/ShackHartmann.py:605-672) */
     int32_t pyr_n_res;       /* Pyramid: padded FFT size nRes (OOPAO/Pyramid.py:251) */
-    int32_t pyr_n_theta;     /* Pyramid: modulation points (1 = unmodulated) */
+    int32_t pyr_n_theta;     /* Pyramid: modulation points (1 = unmodulated, OOPAO/Pyramid.py:955, 976) */
+    int32_t pyr_centering;   /* Pyramid: 1 = psfCentering (mask on 4 pixels, phasor), 0 = fftshift + 1-pixel mask */
+    int32_t pyr_norm_valid;  /* Pyramid: 0 = 'slopesMaps_incidence_flux' (norm = frame.mean()), 1 = 'slopesMaps' */
+    int32_t pyr_q_lo;        /* Pyramid: first row/column of quadrants 1 (and of the low side of 2, 4) in the frame */
+    int32_t pyr_q_hi;        /* Pyramid: first row/column of the high-side quadrants (grabQuadrant, OOPAO/Pyramid.py:774-790) */
     double  atm_wavelength;  /* 500e-9: wavelength the screens are expressed at (OOPAO/Atmosphere.py:134) */
     double  src_wavelength;  /* guide-star wavelength (OOPAO/Source.py:102) */
     double  leak;            /* leaky-integrator factor (MAIN/OOPAOEnv/OOPAOEnv.py:69) */
@@ -78,10 +82,14 @@ enum AoConst {
     AOENV_C_DM_MODES,        /* [f64 R*R*A]    dense influence matrix dm.modes (only if !dm_separable)  */
     AOENV_C_ACT_IDX,         /* [i32 A]        iy*n_act+ix of each valid actuator (xvalid,yvalid)       */
     AOENV_C_WFS_AMP,         /* [f64 R*R]      sqrt(src.fluxMap) (x pupilReflectivity)                  */
-    AOENV_C_SH_SUBAP_IDX,    /* [i32 n_valid_subap] i*n_subap+j of each valid lenslet                   */
-    AOENV_C_SH_REF,          /* [f64 2*n_valid_subap] reference centroids (x block then y block)        */
+    AOENV_C_SH_SUBAP_IDX,    /* [i32 n_valid_subap] SH: i*n_subap+j of each valid lenslet;
+                                                    Pyramid: r*n_subap+c of each valid pixel of a quadrant (validI4Q) */
+    AOENV_C_SH_REF,          /* [f64 2*n_valid_subap] SH: reference centroids (x block then y block);
+                                                      Pyramid: referenceSignal_2D at the valid pixels             */
     AOENV_C_WFS_UNITS,       /* [f64 1]        slopes_units                                             */
     AOENV_C_RECON,           /* [f64 A*n_signal] reconstructor = M2C @ calib.M (MAIN/OOPAOEnv/OOPAOEnv.py:381) */
+    AOENV_C_PYR_MASK,        /* [f64 nRes*nRes*2] exp(i m) of the pyramid mask, rounded to complex64 (OOPAO/Pyramid.py:323) */
+    AOENV_C_PYR_TT,          /* [f64 n_theta*R*R] modulation tip/tilt phases, float32-rounded (OOPAO/Pyramid.py:964-970) */
     AOENV_C_COUNT
 };
 
@@ -190,7 +198,7 @@ int aoenv_set_option(AoEnv* env, int option, int value);
  * AoKernel.  aoenv_profile(env, 0|1) also clears the recorded events. */
 enum AoKernel {
     AOENV_K_SHIFT_GATHER = 0, AOENV_K_MT_NORMAL, AOENV_K_GEMM_RING, AOENV_K_SCATTER, AOENV_K_PHASE,
-    AOENV_K_SH_SPOTS, AOENV_K_SH_CENTROID, AOENV_K_GEMM_RECON, AOENV_K_RECON_FINISH, AOENV_K_COUNT
+    AOENV_K_SH_SPOTS, AOENV_K_SH_CENTROID, AOENV_K_GEMM_RECON, AOENV_K_RECON_FINISH, AOENV_K_PYRAMID, AOENV_K_COUNT
 };
 int aoenv_profile(AoEnv* env, int enable);
 int aoenv_profile_read(AoEnv* env, double* h_ms, int32_t* h_count, void* stream);

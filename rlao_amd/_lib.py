@@ -8,27 +8,27 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AOENV_LIB") or os.path.join(_HERE, "csrc", "libaoenv.so")   # AOENV_LIB: A/B kernel builds
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 F32, F64 = 0, 1
 WFS_SH, WFS_PYRAMID = 0, 1
 
 # enum AoConst
 (C_PUPIL, C_AB, C_INNER_IDX, C_OUTER_IDX, C_LAYER_WEIGHT, C_DM_GX, C_DM_GY, C_DM_MODES, C_ACT_IDX, C_WFS_AMP,
- C_SH_SUBAP_IDX, C_SH_REF, C_WFS_UNITS, C_RECON) = range(14)
+ C_SH_SUBAP_IDX, C_SH_REF, C_WFS_UNITS, C_RECON, C_PYR_MASK, C_PYR_TT) = range(16)
 # enum AoBuf
 (B_SCREEN, B_OPD_ATM, B_COEFS, B_PHASE, B_FRAME, B_SIGNAL, B_TOTAL, B_RESIDUAL, B_WFS_MAX, B_XI) = range(10)
 
 
 OPT_FAST_WFS, OPT_MFMA_GEMM, OPT_FAST_TRIG, OPT_STORE_ATM_OPD = 0, 1, 2, 3
 KERNEL_NAMES = ("shift_gather", "mt_normal", "gemm_ring", "scatter_minmax", "phase", "sh_spots", "sh_centroid",
-                "gemm_recon", "recon_finish")
+                "gemm_recon", "recon_finish", "pyramid")
 
 
 class AoCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "abi_version", "dtype", "n_env", "resolution", "n_layer", "layer_res", "n_inner", "n_outer", "n_act",
         "n_valid_act", "dm_separable", "wfs_type", "n_subap", "n_valid_subap", "n_signal", "cam_res", "n_loop",
-        "max_group", "pyr_n_res", "pyr_n_theta")] + [(n, C.c_double) for n in (
+        "max_group", "pyr_n_res", "pyr_n_theta", "pyr_centering", "pyr_norm_valid", "pyr_q_lo", "pyr_q_hi")] + [(n, C.c_double) for n in (
             "atm_wavelength", "src_wavelength", "leak", "threshold_cog")]
 
 

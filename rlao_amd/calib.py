@@ -57,7 +57,11 @@ class AOParams:
     nLoop: int = 10000
     gainCL: float = 0.5
     leak: float = 0.99
-    lightThreshold: float = 0.5          # SH lightRatio (MAIN/OOPAOEnv/OOPAOEnvRazor.py:236)
+    lightThreshold: float = None         # SH lightRatio 0.5 (MAIN/OOPAOEnv/OOPAOEnvRazor.py:236); Pyramid 0.1 (parameterFile:67)
+    modulation: float = 0.0              # Pyramid modulation radius in lambda/D (papyrus_config.yaml:17)
+    n_pix_separation: int = 4            # parameterFile_oopao_parser.py:65
+    psfCentering: bool = True            # Pyramid default used by OOPAOEnv.set_params (the call does not pass it)
+    postProcessing: str = "slopesMaps_incidence_flux"
     threshold_cog: float = 0.01          # OOPAO/ShackHartmann.py:42
     nModes: int = 50                     # Zernike modes kept from the M2C (MAIN/OOPAOEnv/OOPAOEnv.py:260)
     nMeasurements: int = 6               # MAIN/OOPAOEnv/OOPAOEnv.py:285
@@ -278,12 +282,90 @@ class SHTables:
         self.flux_map = pupil.astype(float) * n_photon * p.samplingTime * (p.diameter / R) ** 2   # OOPAO/Source.py:151
         # lenslet k = i*ns + j sees flux_map.T[j*px:(j+1)*px, i*px:(i+1)*px]  (:331-335)
         per = self.flux_map.T.reshape(ns, px, ns, px).sum(axis=(1, 3)).T.reshape(-1)
-        self.valid_1d = per >= p.lightThreshold * per.max()
+        self.valid_1d = per >= (0.5 if p.lightThreshold is None else p.lightThreshold) * per.max()
         self.valid_2d = self.valid_1d.reshape(ns, ns)
         self.subap_idx = np.flatnonzero(self.valid_1d).astype(np.int32)
         self.nValid = int(self.subap_idx.size)
         self.nSignal = 2 * self.nValid
         self.amp = np.sqrt(self.flux_map)
+
+
+# ------------------------------------------------------------------------------------------------------
+# Pyramid geometry
+# ------------------------------------------------------------------------------------------------------
+class PyramidTables:
+    """Sizes, focal-plane mask, modulation path and quadrant geometry of the Pyramid WFS
+    (OOPAO/Pyramid.py:251-297 sizes, :368-405 mask, :941-976 modulation, :774-790 quadrants)."""
+
+    def __init__(self, p: AOParams, pupil: np.ndarray, n_photon: float, psf_centering: bool = True,
+                 n_pix_separation: int = 4, n_pix_edge: int = 2, calib_modulation: float = 50,
+                 post_processing: str = "slopesMaps_incidence_flux"):
+        R, ns = p.resolution, p.nSubaperture
+        if (R / ns) % 2 != 0:
+            raise ValueError("The resolution should be an even number and be a multiple of 2**i where i>=2")   # :210-211
+        if post_processing not in ("slopesMaps", "slopesMaps_incidence_flux"):
+            raise NotImplementedError("only the slopes-maps post-processings are built (full-frame modes are out of scope)")
+        self.R, self.nSubap = R, ns
+        self.psf_centering = bool(psf_centering)
+        self.norm_valid = 1 if post_processing == "slopesMaps" else 0
+        self.n_pix_separation, self.n_pix_edge = n_pix_separation, n_pix_edge
+        self.nRes = int((ns * 2 + n_pix_separation + n_pix_edge * 2) * R / ns)
+        self.cam_res = round(ns * (self.nRes / R))
+        self.calib_modulation = R / 2 - 1 if calib_modulation >= R / 2 else calib_modulation
+        self.pupil_f = pupil.astype(float)
+        self.flux_map = self.pupil_f * n_photon * p.samplingTime * (p.diameter / R) ** 2
+        tip, tilt = np.meshgrid(np.linspace(-np.pi, np.pi, R), np.linspace(-np.pi, np.pi, R))
+        self.Tip, self.Tilt = tip * self.pupil_f, tilt * self.pupil_f
+        ne = int(np.round((n_pix_separation / ns) * R / (R / ns) / 2))
+        c = int(np.round(self.cam_res / 2))
+        self.q_lo, self.q_hi = c - ne - int(np.ceil(ns)), c + ne
+        self.m = self._phase_mask()
+        mk = np.complex64(np.exp(1j * self.m))                       # complex64, as the reference stores it (:323)
+        self.mask_pairs = np.stack([mk.real.astype(np.float64), mk.imag.astype(np.float64)], axis=-1)
+
+    def _phase_mask(self) -> np.ndarray:
+        n_tot, ns, sep = self.nRes, self.nSubap, self.n_pix_separation
+        norma = (ns + sep) * (self.R / ns)
+        m = np.zeros([n_tot, n_tot])
+        h = n_tot // 2
+        if self.psf_centering:                                        # mask centred on 4 pixels
+            lim = np.pi / 4 - np.pi / 4 / h
+            a, b = np.meshgrid(np.linspace(-lim, lim, h), np.linspace(-lim, lim, h))
+            m[:h, :h] = a * norma + b * norma
+            m[:h, -h:] = -a * norma + b * norma
+            m[-h:, -h:] = -a * norma + -b * norma
+            m[-h:, :h] = a * norma + -b * norma
+        else:                                                         # mask centred on 1 pixel
+            d_pix = (np.pi / 4) / (n_tot / 2)
+            lp, lm = np.pi / 4, np.pi / 4 - 2 * d_pix
+            t1, u1 = np.meshgrid(np.linspace(-lp, lp, h + 1), np.linspace(-lp, lp, h + 1))
+            t2, u2 = np.meshgrid(np.linspace(-lp, lp, h + 1), np.linspace(-lm, lm, h - 1))
+            t3, u3 = np.meshgrid(np.linspace(-lm, lm, h - 1), np.linspace(-lm, lm, h - 1))
+            t4, u4 = np.meshgrid(np.linspace(-lm, lm, h - 1), np.linspace(-lp, lp, h + 1))
+            m[:h + 1, :h + 1] = t1 * norma + u1 * norma
+            m[:h + 1, -h + 1:] = -t4 * norma + u4 * norma
+            m[-h + 1:, -h + 1:] = -t3 * norma + -u3 * norma
+            m[-h + 1:, :h + 1] = t2 * norma + -u2 * norma
+        return -m
+
+    def modulation_table(self, modulation: float):
+        """(nTheta, tt[nTheta, R, R]) -- the tip/tilt phases are float32 in the reference (:964-970)."""
+        if modulation == 0:
+            return 1, None
+        n_theta = 4 * int(0 + np.ceil(np.pi * 2 * modulation / 4))
+        theta = np.linspace(0, 2 * np.pi, n_theta, endpoint=False)
+        buf = np.zeros([n_theta, self.R, self.R]).astype(np.float32)
+        for i in range(n_theta):
+            buf[i] = (modulation * np.cos(theta[i]) * self.Tip + modulation * np.sin(theta[i]) * self.Tilt) * self.pupil_f
+        return n_theta, buf.astype(np.float64)
+
+    def amplitude(self, n_theta: int) -> np.ndarray:
+        return np.sqrt(self.flux_map / n_theta) * self.pupil_f       # :520
+
+    def quadrant_sum(self, frame: np.ndarray) -> np.ndarray:
+        lo, hi, p = self.q_lo, self.q_hi, self.nSubap
+        return (frame[lo:lo + p, lo:lo + p] + frame[lo:lo + p, hi:hi + p] + frame[hi:hi + p, hi:hi + p]
+                + frame[hi:hi + p, lo:lo + p])
 
 
 def tip_ramp(R: int) -> np.ndarray:

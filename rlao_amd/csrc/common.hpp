@@ -139,4 +139,38 @@ int launch_recon_finish(const FinishArgs<T>& fa, int n_env, hipStream_t st);
 template <typename T>
 int launch_convert_from_f64(const double* src, T* dst, size_t n, hipStream_t st);
 
+// ---- Pyramid WFS (pyr_kernels.hip) ---------------------------------------------------------------------
+template <typename T> struct cx;
+struct FftPlan {
+    int n;            // transform length
+    int n_fac;        // number of stages
+    int fac[12];      // radix of each stage, product = n
+};
+int make_fft_plan(int n, FftPlan* pl);
+template <typename T>
+struct PyrArgs {
+    const T* phase;        // [E][R*R]
+    const T* amp;          // [R*R]   sqrt(flux / nTheta) * reflectivity
+    const T* tt;           // [nTheta][R*R] modulation tip/tilt (float32-rounded in the reference) or null
+    const T* mask;         // [N*N][2] exp(i m), complex64-rounded
+    const T* tw;           // [N][2]
+    cx<T>* t1;             // [E][chunk][R][N]
+    cx<T>* t2;             // [E][chunk][N][N]
+    T* frame;              // [E][cam*cam]
+    FftPlan plan;
+    int R, N, cam, off, centering, theta0, n_theta_chunk, n_env, seq_per_block;
+};
+template <typename T>
+struct PyrSlopeArgs {
+    const T* frame;          // [E][cam*cam]
+    const int* valid_idx;    // [nValid] r * nSub + c inside a quadrant
+    const T* ref;            // [2*nValid] reference slopes at the valid pixels (x block, y block)
+    T* signal;               // [E][2*nValid]
+    int cam, n_sub, n_valid, q_lo, q_hi;   // quadrant origins (grabQuadrant)
+    int norm_valid_mean;     // 0: frame.mean() ; 1: mean of I1+I2+I3+I4 over the valid pixels
+    T units;
+};
+template <typename T>
+int launch_pyramid(const PyrArgs<T>& base, const PyrSlopeArgs<T>& sl, int n_theta, int chunk, hipStream_t st);
+
 }  // namespace ao

@@ -76,6 +76,14 @@ struct AoEnv {
     void* frame = nullptr;
     void* signal = nullptr;
     void* recon = nullptr;                  // [A][nSig]
+    // Pyramid
+    void* pyr_mask = nullptr;               // [N*N][2]
+    void* pyr_tt = nullptr;                 // [nTheta][R*R]
+    void* pyr_tw = nullptr;                 // [N][2]
+    void* pyr_t1 = nullptr;                 // [E][chunk][R][N] complex
+    void* pyr_t2 = nullptr;                 // [E][chunk][N][N] complex
+    FftPlan pyr_plan{};
+    int pyr_chunk = 1;
     void* vbuf = nullptr;                   // [E][A]
     void* obs_scratch = nullptr;            // [E][nAct*nAct]
     std::vector<void*> allocs;
@@ -280,7 +288,40 @@ int run_phase(AoEnv* env, int update_atm, int store_atm, hipStream_t st, int sto
 
 template <typename T>
 int run_wfs(AoEnv* env, hipStream_t st) {
-    if (env->c.wfs_type != AOENV_WFS_SH) return fail("wfs_type %d is not implemented in this build", env->c.wfs_type);
+    if (env->c.wfs_type == AOENV_WFS_PYRAMID) {
+        if (!env->have[AOENV_C_PYR_MASK] || (env->c.pyr_n_theta > 1 && !env->have[AOENV_C_PYR_TT]))
+            return fail("pyramid mask / modulation table has not been uploaded");
+        PyrArgs<T> pa{};
+        pa.phase = env->as<T>(env->phase);
+        pa.amp = env->as<T>(env->amp);
+        pa.tt = env->c.pyr_n_theta > 1 ? env->as<T>(env->pyr_tt) : nullptr;
+        pa.mask = env->as<T>(env->pyr_mask);
+        pa.tw = env->as<T>(env->pyr_tw);
+        pa.t1 = reinterpret_cast<cx<T>*>(env->pyr_t1);
+        pa.t2 = reinterpret_cast<cx<T>*>(env->pyr_t2);
+        pa.frame = env->as<T>(env->frame);
+        pa.plan = env->pyr_plan;
+        pa.R = env->R;
+        pa.N = env->c.pyr_n_res;
+        pa.cam = env->c.cam_res;
+        pa.off = env->c.pyr_n_res / 2 - env->R / 2;
+        pa.centering = env->c.pyr_centering;
+        pa.n_env = env->E;
+        PyrSlopeArgs<T> sl{};
+        sl.frame = env->as<T>(env->frame);
+        sl.valid_idx = env->subap_idx;
+        sl.ref = env->as<T>(env->sh_ref);
+        sl.signal = env->as<T>(env->signal);
+        sl.cam = env->c.cam_res;
+        sl.n_sub = env->nSub;
+        sl.n_valid = env->nVal;
+        sl.q_lo = env->c.pyr_q_lo;
+        sl.q_hi = env->c.pyr_q_hi;
+        sl.norm_valid_mean = env->c.pyr_norm_valid;
+        sl.units = (T)env->units;
+        AO_PROF(env, PYRAMID, st);
+        return launch_pyramid<T>(pa, sl, env->c.pyr_n_theta, env->pyr_chunk, st);
+    }
     const ShConst<T> sc = sh_const<T>(env);
     {
         AO_PROF(env, SH_SPOTS, st);
@@ -404,7 +445,14 @@ int aoenv_create(const AoCfg* cfg, int device, AoEnv** out) {
         if (cfg->n_inner != 8 * cfg->layer_res - 16 || cfg->n_outer != 4 * cfg->layer_res + 4)
             return fail("n_inner / n_outer do not match layer_res");
     }
-    if (cfg->wfs_type == AOENV_WFS_SH && cfg->n_signal != 2 * cfg->n_valid_subap) return fail("n_signal != 2 n_valid_subap");
+    if (cfg->n_signal != 2 * cfg->n_valid_subap) return fail("n_signal != 2 n_valid_subap");
+    if (cfg->wfs_type != AOENV_WFS_SH && cfg->wfs_type != AOENV_WFS_PYRAMID) return fail("unknown wfs_type %d", cfg->wfs_type);
+    if (cfg->wfs_type == AOENV_WFS_PYRAMID) {
+        if (cfg->pyr_n_res < cfg->resolution || cfg->pyr_n_res % 2 || cfg->cam_res < 1 || cfg->pyr_n_res % cfg->cam_res)
+            return fail("pyramid: nRes %d must be even, >= R and a multiple of the camera size %d", cfg->pyr_n_res, cfg->cam_res);
+        if (cfg->pyr_n_theta < 1) return fail("pyramid: n_theta must be >= 1");
+        if (cfg->pyr_q_lo < 0 || cfg->pyr_q_hi + cfg->n_subap > cfg->cam_res) return fail("pyramid: quadrants outside the camera");
+    }
     if (cfg->max_group < 1) return fail("max_group must be >= 1");
     int ndev = 0;
     AO_HIP(hipGetDeviceCount(&ndev));
@@ -462,6 +510,15 @@ int aoenv_create(const AoCfg* cfg, int device, AoEnv** out) {
     A_(&e->frame, E * (size_t)cfg->cam_res * cfg->cam_res * z);
     A_(&e->signal, E * e->nSig * z);
     A_(&e->recon, (size_t)e->A * e->nSig * z);
+    if (cfg->wfs_type == AOENV_WFS_PYRAMID) {
+        const size_t N = cfg->pyr_n_res;
+        e->pyr_chunk = cfg->pyr_n_theta < 4 ? cfg->pyr_n_theta : 4;
+        A_(&e->pyr_mask, N * N * 2 * z);
+        A_(&e->pyr_tt, (size_t)cfg->pyr_n_theta * R2 * z);
+        A_(&e->pyr_tw, N * 2 * z);
+        A_(&e->pyr_t1, E * e->pyr_chunk * (size_t)e->R * N * 2 * z);
+        A_(&e->pyr_t2, E * e->pyr_chunk * N * N * 2 * z);
+    }
     A_(&e->vbuf, (size_t)kMaxSplits * E * e->A * z);
     A_(&e->obs_scratch, E * (size_t)e->nAct * e->nAct * z);
     if (rc) { aoenv_destroy(e); return rc; }
@@ -479,6 +536,15 @@ int aoenv_create(const AoCfg* cfg, int device, AoEnv** out) {
         }
         rc = upload_real(e, e->tw, tw.data(), tw.size());
         if (!rc) rc = upload_real(e, e->phs, ph.data(), ph.size());
+        if (rc) { aoenv_destroy(e); return rc; }
+    }
+    if (cfg->wfs_type == AOENV_WFS_PYRAMID) {
+        const int N = cfg->pyr_n_res;
+        rc = make_fft_plan(N, &e->pyr_plan);
+        std::vector<double> tw(2 * (size_t)N);
+        const double pi = 3.14159265358979323846;
+        for (int k = 0; k < N; ++k) { tw[2 * k] = std::cos(2 * pi * k / N); tw[2 * k + 1] = -std::sin(2 * pi * k / N); }
+        if (!rc) rc = upload_real(e, e->pyr_tw, tw.data(), tw.size());
         if (rc) { aoenv_destroy(e); return rc; }
     }
     *out = e;
@@ -587,6 +653,20 @@ int aoenv_upload(AoEnv* env, int kind, const void* h, size_t bytes) {
             AO_TRY(need((size_t)env->A * env->nSig * 8));
             AO_TRY(upload_real(env, env->recon, d, (size_t)env->A * env->nSig));
             break;
+        case AOENV_C_PYR_MASK: {
+            if (env->c.wfs_type != AOENV_WFS_PYRAMID) return fail("not a pyramid shard");
+            const size_t n = (size_t)env->c.pyr_n_res * env->c.pyr_n_res * 2;
+            AO_TRY(need(n * 8));
+            AO_TRY(upload_real(env, env->pyr_mask, d, n));
+            break;
+        }
+        case AOENV_C_PYR_TT: {
+            if (env->c.wfs_type != AOENV_WFS_PYRAMID) return fail("not a pyramid shard");
+            const size_t n = (size_t)env->c.pyr_n_theta * R2;
+            AO_TRY(need(n * 8));
+            AO_TRY(upload_real(env, env->pyr_tt, d, n));
+            break;
+        }
         default: return fail("unknown constant id %d", kind);
     }
     env->have[kind] = true;

@@ -1,0 +1,321 @@
+// Pyramid wave-front sensor: zero-padded 2-D FFT -> 4-facet phase mask -> inverse 2-D FFT -> |.|^2 summed over the
+// modulation points -> camera binning -> quadrant slopes maps.
+//   OOPAO/Pyramid.py:469-504  pyramid_transform      :516-607  wfs_measure (single wave-front, modulation loop)
+//   OOPAO/Pyramid.py:987-1006 camera binning         :682-725, 774-790  signalProcessing / grabQuadrant
+//
+// nRes = (2 nSub + sep + 2 edge) px is not a power of two (288 = 2^5 3^2 for 20 sub-apertures, 528 = 2^4 3 11 for 40)
+// and an nRes^2 complex field (0.66 / 2.2 MB) does not fit in LDS, so the 2-D transforms are done as 1-D passes of
+// whole rows / columns held in LDS, three kernels per modulation chunk:
+//   P1 rows   : build E = amp exp(i(phi + TT_theta)) [x phasor] for a few pupil rows, zero-pad, FFT along x.  Only the
+//               R pupil rows are non-zero, so only R of the nRes rows are transformed and stored (T1: R x nRes).
+//   P2 columns: FFT along y of a few columns (zero-padded from R to nRes), fftshift + mask multiply in LDS, and --
+//               since the column is already resident -- the inverse FFT along y right away (T2: nRes x nRes).
+//   P3 rows   : inverse FFT along x of the nRes/cam rows that feed one camera row, |.|^2 / nRes^4, sum over the
+//               modulation points of the chunk, bin to the camera row, accumulate into the frame.
+// The 1-D FFT is a Stockham autosort with the radix list chosen on the host (4, 2, 3, 5, then any prime factor by a
+// direct butterfly), twiddles from a table w_N^k computed in float64.
+#include "common.hpp"
+
+namespace ao {
+
+template <typename T> struct cx { T re, im; };
+template <typename T> __device__ inline cx<T> cmul(cx<T> a, cx<T> b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+template <typename T> __device__ inline cx<T> cadd(cx<T> a, cx<T> b) { return {a.re + b.re, a.im + b.im}; }
+template <typename T> __device__ inline cx<T> csub(cx<T> a, cx<T> b) { return {a.re - b.re, a.im - b.im}; }
+
+template <typename T> __device__ inline void sincos_g(T x, T* s, T* c);
+template <> __device__ inline void sincos_g<float>(float x, float* s, float* c) { sincosf(x, s, c); }
+template <> __device__ inline void sincos_g<double>(double x, double* s, double* c) { sincos(x, s, c); }
+
+// twiddle w^k, k in [0, n): forward exp(-2 pi i k / n); inverse = conjugate
+template <typename T>
+__device__ inline cx<T> tw_get(const T* __restrict__ tw, int k, int inverse) {
+    cx<T> w = {tw[2 * k], tw[2 * k + 1]};
+    if (inverse) w.im = -w.im;
+    return w;
+}
+
+// One Stockham stage over `nseq` sequences stored [seq][n] in LDS (src -> dst), all lanes of the workgroup cooperate.
+template <typename T, int R>
+__device__ inline void fft_stage_r(const cx<T>* __restrict__ src, cx<T>* __restrict__ dst, int n, int ns, int nseq,
+                                   const T* __restrict__ tw, int inverse) {
+    const int m = n / R;
+    const int tstep = n / (ns * R);                             // w_{ns R}^{k} = w_n^{k tstep}
+    for (int w = threadIdx.x; w < nseq * m; w += blockDim.x) {
+        const int seq = w / m, j = w - seq * m;
+        const int k = j % ns;
+        const cx<T>* s = src + seq * n;
+        cx<T> v[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            v[r] = s[j + r * m];
+            if (r > 0) v[r] = cmul(v[r], tw_get(tw, (k * r * tstep) % n, inverse));
+        }
+        cx<T> y[R];
+        if (R == 2) {
+            y[0] = cadd(v[0], v[1]);
+            y[1] = csub(v[0], v[1]);
+        } else if (R == 4) {
+            const cx<T> a = cadd(v[0], v[2]), b = csub(v[0], v[2]), c = cadd(v[1], v[3]), d = csub(v[1], v[3]);
+            // forward: multiply d by -i ; inverse: by +i
+            const cx<T> dj = inverse ? cx<T>{-d.im, d.re} : cx<T>{d.im, -d.re};
+            y[0] = cadd(a, c);
+            y[1] = cadd(b, dj);
+            y[2] = csub(a, c);
+            y[3] = csub(b, dj);
+        } else {
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                cx<T> acc = v[0];
+#pragma unroll
+                for (int r = 1; r < R; ++r) acc = cadd(acc, cmul(v[r], tw_get(tw, ((q * r) % R) * (n / R), inverse)));
+                y[q] = acc;
+            }
+        }
+        cx<T>* d = dst + seq * n + (j / ns) * ns * R + k;
+#pragma unroll
+        for (int q = 0; q < R; ++q) d[q * ns] = y[q];
+    }
+}
+
+// any other (prime) radix: direct butterfly straight from LDS, no register arrays
+template <typename T>
+__device__ inline void fft_stage_any(const cx<T>* __restrict__ src, cx<T>* __restrict__ dst, int n, int ns, int nseq,
+                                     int R, const T* __restrict__ tw, int inverse) {
+    const int m = n / R;
+    const int tstep = n / (ns * R);
+    for (int w = threadIdx.x; w < nseq * m * R; w += blockDim.x) {
+        const int q = w % R, w2 = w / R;
+        const int seq = w2 / m, j = w2 - seq * m;
+        const int k = j % ns;
+        const cx<T>* s = src + seq * n;
+        cx<T> acc = {0, 0};
+        for (int r = 0; r < R; ++r) {
+            const int idx = ((k * r * tstep) % n + ((q * r) % R) * (n / R)) % n;
+            acc = cadd(acc, cmul(s[j + r * m], tw_get(tw, idx, inverse)));
+        }
+        dst[seq * n + (j / ns) * ns * R + k + q * ns] = acc;
+    }
+}
+
+// Full 1-D transform of `nseq` sequences; returns the buffer that holds the result (a or b).
+template <typename T>
+__device__ inline cx<T>* fft_lds(cx<T>* a, cx<T>* b, const FftPlan& pl, int nseq, const T* __restrict__ tw, int inverse) {
+    int ns = 1;
+    cx<T>* src = a;
+    cx<T>* dst = b;
+    for (int s = 0; s < pl.n_fac; ++s) {
+        const int R = pl.fac[s];
+        __syncthreads();
+        switch (R) {
+            case 2: fft_stage_r<T, 2>(src, dst, pl.n, ns, nseq, tw, inverse); break;
+            case 3: fft_stage_r<T, 3>(src, dst, pl.n, ns, nseq, tw, inverse); break;
+            case 4: fft_stage_r<T, 4>(src, dst, pl.n, ns, nseq, tw, inverse); break;
+            case 5: fft_stage_r<T, 5>(src, dst, pl.n, ns, nseq, tw, inverse); break;
+            default: fft_stage_any<T>(src, dst, pl.n, ns, nseq, R, tw, inverse); break;
+        }
+        ns *= R;
+        cx<T>* t = src;
+        src = dst;
+        dst = t;
+    }
+    __syncthreads();
+    return src;
+}
+
+// P1: grid = (ceil(R / RB), chunk, E)
+template <typename T>
+__global__ void __launch_bounds__(256) k_pyr_rows(const PyrArgs<T> a) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int N = a.N, R = a.R, RB = a.seq_per_block;
+    cx<T>* A = reinterpret_cast<cx<T>*>(lds_raw);
+    cx<T>* B = A + RB * N;
+    const int e = blockIdx.z, th = blockIdx.y, y0 = blockIdx.x * RB;
+    const int nrow = min(RB, R - y0);
+    const T* ph = a.phase + (size_t)e * R * R;
+    const T* tt = a.tt ? a.tt + (size_t)(a.theta0 + th) * R * R : nullptr;
+    const T pi_over_n = (T)(3.14159265358979323846 / N);
+    for (int i = threadIdx.x; i < RB * N; i += blockDim.x) {
+        const int r = i / N, xg = i - r * N;
+        cx<T> v = {0, 0};
+        const int x = xg - a.off;
+        if (r < nrow && x >= 0 && x < R) {
+            const int p = (y0 + r) * R + x;
+            const T am = a.amp[p];
+            if (am != (T)0) {
+                T ang = ph[p];
+                if (tt) ang += tt[p];
+                // centred mask: the field is multiplied by exp(-i pi (N+1)/N (x + y)) on the padded grid (Pyramid.py:294, 486)
+                // the angle pi (N+1) k / N is reduced mod 2 pi in integers (k up to 2N would cost float32 1e-4 rad)
+                if (a.centering) ang -= pi_over_n * (T)(((N + 1) * (xg + y0 + r + a.off)) % (2 * N));
+                T s, c;
+                sincos_g<T>(ang, &s, &c);
+                v = {am * c, am * s};
+            }
+        }
+        A[i] = v;
+    }
+    cx<T>* out = fft_lds<T>(A, B, a.plan, RB, a.tw, 0);
+    cx<T>* t1 = a.t1 + (((size_t)e * a.n_theta_chunk + th) * R + y0) * N;
+    for (int i = threadIdx.x; i < nrow * N; i += blockDim.x) t1[i] = out[i];
+}
+
+// P2: grid = (N / CB, chunk, E); CB columns per workgroup
+template <typename T>
+__global__ void __launch_bounds__(256) k_pyr_cols(const PyrArgs<T> a) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int N = a.N, R = a.R, CB = a.seq_per_block;
+    cx<T>* A = reinterpret_cast<cx<T>*>(lds_raw);
+    cx<T>* B = A + CB * N;
+    const int e = blockIdx.z, th = blockIdx.y, kx0 = blockIdx.x * CB;
+    const cx<T>* t1 = a.t1 + ((size_t)e * a.n_theta_chunk + th) * R * N;
+    // gather: sequence c = column kx0 + c, element y (zero outside the pupil rows)
+    for (int i = threadIdx.x; i < CB * N; i += blockDim.x) A[i] = {0, 0};
+    __syncthreads();
+    for (int i = threadIdx.x; i < R * CB; i += blockDim.x) {
+        const int y = i / CB, c = i - y * CB;                     // lanes along the columns: contiguous in T1
+        A[c * N + a.off + y] = t1[(size_t)y * N + kx0 + c];
+    }
+    cx<T>* f = fft_lds<T>(A, B, a.plan, CB, a.tw, 0);
+    cx<T>* g = (f == A) ? B : A;
+    // focal plane: [fftshift] + mask   (Pyramid.py:486-497).  Shifted position i holds frequency (i + N/2) mod N.
+    const int h = a.centering ? 0 : N / 2;
+    for (int i = threadIdx.x; i < CB * N; i += blockDim.x) {
+        const int c = i / N, ky = i - c * N;                      // output (shifted) row index ky
+        const int jx = (kx0 + c + h) % N;                         // output (shifted) column of frequency kx0 + c
+        const cx<T> v = f[c * N + (ky + h) % N];
+        const T* mk = a.mask + 2 * ((size_t)ky * N + jx);
+        g[i] = cmul(v, cx<T>{mk[0], mk[1]});
+    }
+    cx<T>* r = fft_lds<T>(g, f, a.plan, CB, a.tw, 1);
+    cx<T>* t2 = a.t2 + ((size_t)e * a.n_theta_chunk + th) * N * N;
+    const int jx0 = (kx0 + h) % N;                                // CB divides N/2: the block's columns stay contiguous
+    for (int i = threadIdx.x; i < N * CB; i += blockDim.x) {
+        const int ky = i / CB, c = i - ky * CB;
+        t2[(size_t)ky * N + jx0 + c] = r[c * N + ky];
+    }
+}
+
+// P3: grid = (cam, E); the nb = N / cam rows of one camera row, all modulation points of the chunk
+template <typename T>
+__global__ void __launch_bounds__(256) k_pyr_rows_inv(const PyrArgs<T> a, int accumulate) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int N = a.N, nb = N / a.cam;
+    cx<T>* A = reinterpret_cast<cx<T>*>(lds_raw);
+    cx<T>* B = A + nb * N;
+    T* acc = reinterpret_cast<T*>(B + nb * N);                    // [N] column sums of |.|^2 over the nb rows and the chunk
+    const int e = blockIdx.y, cr = blockIdx.x;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) acc[i] = (T)0;
+    const T scale = (T)1 / ((T)N * (T)N * (T)N * (T)N);            // ifft2 normalisation 1/N^2 on the amplitude
+    for (int th = 0; th < a.n_theta_chunk; ++th) {
+        const cx<T>* t2 = a.t2 + (((size_t)e * a.n_theta_chunk + th) * N + (size_t)cr * nb) * N;
+        __syncthreads();
+        for (int i = threadIdx.x; i < nb * N; i += blockDim.x) A[i] = t2[i];
+        cx<T>* r = fft_lds<T>(A, B, a.plan, nb, a.tw, 1);
+        for (int x = threadIdx.x; x < N; x += blockDim.x) {
+            T s = 0;
+            for (int q = 0; q < nb; ++q) {
+                const cx<T> v = r[q * N + x];
+                s += (v.re * v.re + v.im * v.im) * scale;
+            }
+            acc[x] += s;
+        }
+    }
+    __syncthreads();
+    T* fr = a.frame + (size_t)e * a.cam * a.cam + (size_t)cr * a.cam;
+    for (int c = threadIdx.x; c < a.cam; c += blockDim.x) {
+        T s = 0;
+        for (int q = 0; q < nb; ++q) s += acc[c * nb + q];
+        fr[c] = accumulate ? fr[c] + s : s;
+    }
+}
+
+// Slopes maps, one workgroup per env (Pyramid.py:703-725 'slopesMaps_incidence_flux', :685-701 'slopesMaps').
+template <typename T>
+__global__ void __launch_bounds__(256) k_pyr_slopes(const PyrSlopeArgs<T> a) {
+    __shared__ double red[4];
+    const int e = blockIdx.x;
+    const T* fr = a.frame + (size_t)e * a.cam * a.cam;
+    double s = 0;
+    if (!a.norm_valid_mean) {
+        for (int i = threadIdx.x; i < a.cam * a.cam; i += blockDim.x) s += (double)fr[i];
+    } else {
+        for (int k = threadIdx.x; k < a.n_valid; k += blockDim.x) {
+            const int r = a.valid_idx[k] / a.n_sub, c = a.valid_idx[k] % a.n_sub;
+            s += (double)fr[(a.q_lo + r) * a.cam + a.q_lo + c] + (double)fr[(a.q_lo + r) * a.cam + a.q_hi + c] +
+                 (double)fr[(a.q_hi + r) * a.cam + a.q_hi + c] + (double)fr[(a.q_hi + r) * a.cam + a.q_lo + c];
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x / kWave] = s;
+    __syncthreads();
+    const double tot = red[0] + red[1] + red[2] + red[3];
+    const T norma = (T)(a.norm_valid_mean ? tot / a.n_valid : tot / ((double)a.cam * a.cam));
+    T* sg = a.signal + (size_t)e * 2 * a.n_valid;
+    for (int k = threadIdx.x; k < a.n_valid; k += blockDim.x) {
+        const int r = a.valid_idx[k] / a.n_sub, c = a.valid_idx[k] % a.n_sub;
+        const T i1 = fr[(a.q_lo + r) * a.cam + a.q_lo + c];      // grabQuadrant(1): rows lo, cols lo
+        const T i2 = fr[(a.q_lo + r) * a.cam + a.q_hi + c];      // (2): rows lo, cols hi
+        const T i3 = fr[(a.q_hi + r) * a.cam + a.q_hi + c];      // (3): rows hi, cols hi
+        const T i4 = fr[(a.q_hi + r) * a.cam + a.q_lo + c];      // (4): rows hi, cols lo
+        const T sx = ((i1 - i2) + i4) - i3;
+        const T sy = ((i1 - i4) + i2) - i3;
+        sg[k] = (sx / norma - a.ref[k]) * a.units;
+        sg[a.n_valid + k] = (sy / norma - a.ref[a.n_valid + k]) * a.units;
+    }
+}
+
+template <typename T>
+int launch_pyramid(const PyrArgs<T>& base, const PyrSlopeArgs<T>& sl, int n_theta, int chunk, hipStream_t st) {
+    PyrArgs<T> a = base;
+    const int N = a.N, R = a.R;
+    // sequences per workgroup: keep the two LDS buffers within 64 KiB (P3 may need more: raised explicitly)
+    int rb = (int)(64 * 1024 / (2 * (size_t)N * sizeof(cx<T>)));
+    if (rb < 1) return fail("pyramid: nRes = %d does not fit two LDS row buffers", N);
+    rb = rb > 8 ? 8 : rb;
+    int cb = rb;
+    while (cb > 1 && (N / 2) % cb) --cb;                          // CB must divide N/2 (fftshift keeps a block's columns contiguous)
+    const int nb = N / a.cam;
+    const size_t lds3 = (size_t)(2 * nb * N) * sizeof(cx<T>) + (size_t)N * sizeof(T);
+    if (lds3 > 160 * 1024) return fail("pyramid: %d rows of nRes = %d per camera row do not fit in LDS", nb, N);
+    if (lds3 > 64 * 1024)
+        AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyr_rows_inv<T>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+    for (int t0 = 0; t0 < n_theta; t0 += chunk) {
+        a.theta0 = t0;
+        a.n_theta_chunk = (n_theta - t0) < chunk ? (n_theta - t0) : chunk;
+        a.seq_per_block = rb;
+        hipLaunchKernelGGL(k_pyr_rows<T>, dim3(cdiv(R, rb), a.n_theta_chunk, a.n_env), dim3(256),
+                           2 * (size_t)rb * N * sizeof(cx<T>), st, a);
+        a.seq_per_block = cb;
+        hipLaunchKernelGGL(k_pyr_cols<T>, dim3(N / cb, a.n_theta_chunk, a.n_env), dim3(256),
+                           2 * (size_t)cb * N * sizeof(cx<T>), st, a);
+        hipLaunchKernelGGL(k_pyr_rows_inv<T>, dim3(a.cam, a.n_env), dim3(256), lds3, st, a, t0 > 0 ? 1 : 0);
+        AO_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_pyr_slopes<T>, dim3(a.n_env), dim3(256), 0, st, sl);
+    AO_HIP(hipGetLastError());
+    return 0;
+}
+
+template int launch_pyramid<float>(const PyrArgs<float>&, const PyrSlopeArgs<float>&, int, int, hipStream_t);
+template int launch_pyramid<double>(const PyrArgs<double>&, const PyrSlopeArgs<double>&, int, int, hipStream_t);
+
+// radix list for the Stockham transform: 4s first, then 2, 3, 5, then whatever prime factors remain
+int make_fft_plan(int n, FftPlan* pl) {
+    pl->n = n;
+    pl->n_fac = 0;
+    int m = n;
+    auto push = [&](int r) { if (pl->n_fac < 12) pl->fac[pl->n_fac++] = r; };
+    while (m % 4 == 0) { push(4); m /= 4; }
+    while (m % 2 == 0) { push(2); m /= 2; }
+    while (m % 3 == 0) { push(3); m /= 3; }
+    while (m % 5 == 0) { push(5); m /= 5; }
+    for (int p = 7; m > 1; p += 2)
+        while (m % p == 0) { push(p); m /= p; }
+    int prod = 1;
+    for (int i = 0; i < pl->n_fac; ++i) prod *= pl->fac[i];
+    return prod == n ? 0 : fail("cannot factor the FFT length %d into at most 12 stages", n);
+}
+
+}  // namespace ao

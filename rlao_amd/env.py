@@ -34,7 +34,9 @@ class Shard:
 
     def __init__(self, cfg: dict, device: int):
         self.lib = L.load()
-        self.cfg = L.AoCfg(abi_version=L.ABI_VERSION, pyr_n_res=0, pyr_n_theta=1, **cfg)
+        full = dict(pyr_n_res=0, pyr_n_theta=1, pyr_centering=0, pyr_norm_valid=0, pyr_q_lo=0, pyr_q_hi=0)
+        full.update(cfg)
+        self.cfg = L.AoCfg(abi_version=L.ABI_VERSION, **full)
         self.device = device
         self.np_dtype = np.float32 if cfg["dtype"] == L.F32 else np.float64
         h = C.c_void_p()
@@ -342,9 +344,15 @@ class BatchedAOEnv:
         """Kept for call compatibility (MAIN/PO4AO/mbrl.py:27); the parameters come from ``set_params``."""
         self.param_file, self.oopao_path = param_file, oopao_path
 
-    def set_params(self, args=None, wfs_type="shackhartmann", modal_basis="zernike", gainCL=0.5, m2c=None, **kw):
-        if wfs_type not in ("shackhartmann", "sh"):
-            raise NotImplementedError("only the Shack-Hartmann WFS is built so far (Pyramid: SURVEY.md K5)")
+    def set_params(self, args=None, wfs_type="pyramid", modal_basis="zernike", gainCL=0.5, m2c=None, **kw):
+        """Builds the loop (MAIN/OOPAOEnv/OOPAOEnv.py:93-385).  ``wfs_type`` is "pyramid" (the reference's default,
+        Papyrus) or "shackhartmann" (OOPAOEnvRazor.py:232-238)."""
+        if wfs_type in ("shackhartmann", "sh"):
+            self.wfs_type = "sh"
+        elif wfs_type in ("pyramid", "pyr"):
+            self.wfs_type = "pyr"
+        else:
+            raise ValueError(f"unknown wfs_type {wfs_type!r}")
         torch = _torch()
         self.gainCL = gainCL
         p = self.param = calib.params_from_args(args, **kw)
@@ -354,16 +362,22 @@ class BatchedAOEnv:
         self.src_wavelength, self.nPhoton = calib.source(p.opticalBand, p.magnitude)
         self._atm_tables = calib.AtmosphereTables(p)
         self._dm_tables = dmt = calib.DMTables(p)
-        self._sh_tables = sht = calib.SHTables(p, self.pupil, self.nPhoton)
         self.nActuator, self.nValidAct = dmt.nAct, dmt.nValidAct
         self.dm_mask = dmt.dm_mask.astype(int)
         self.xvalid, self.yvalid = dmt.xvalid, dmt.yvalid
-        self.nSignal, self.cam_res = sht.nSignal, sht.cam_res
+        if self.wfs_type == "sh":
+            self._sh_tables = sht = calib.SHTables(p, self.pupil, self.nPhoton)
+            self.nSignal, self.cam_res = sht.nSignal, sht.cam_res
+            self._wfs_valid_idx, self._wfs_n_theta, self._pyr_tt = sht.subap_idx, 1, None
+        else:
+            self._pyr_tables = calib.PyramidTables(p, self.pupil, self.nPhoton, psf_centering=p.psfCentering,
+                                                   n_pix_separation=p.n_pix_separation, post_processing=p.postProcessing)
+            self.cam_res = self._pyr_tables.cam_res
         self._xv_t = torch.as_tensor(self.xvalid, device=self.device)
         self._yv_t = torch.as_tensor(self.yvalid, device=self.device)
 
         # -- calibration on the GPU, float64, same kernels as the loop ------------------------------
-        ref, units = self._calibrate_wfs()
+        ref, units = self._calibrate_wfs() if self.wfs_type == "sh" else self._calibrate_pyramid()
         self.reference_centroids, self.slopes_units = ref, units
         self.imat = self._interaction_matrix(ref, units)
         if m2c is None:
@@ -396,32 +410,82 @@ class BatchedAOEnv:
             if self.return_frame else None
         self.SR = []
         self.atm, self.dm, self.tel, self.wfs = _AtmProxy(self), _DmProxy(self), _TelProxy(self), _WfsProxy(self)
+        self.wfs.tag = "shackHartmann" if self.wfs_type == "sh" else "pyramid"
         # flat measurement, then the initial screens (MAIN/OOPAOEnv/OOPAOEnv.py:312-322)
         self.measure()
         self.generate_new_phase_screen(10)
         return self
 
     def _make_shard(self, n_env, dtype, n_layer, max_group) -> Shard:
-        p, at, dmt, sht = self.param, self._atm_tables, self._dm_tables, self._sh_tables
+        p, at, dmt = self.param, self._atm_tables, self._dm_tables
+        valid_idx = self._wfs_valid_idx
         cfg = dict(dtype=L.F32 if dtype == "f32" else L.F64, n_env=n_env, resolution=self.R, n_layer=n_layer,
                    layer_res=at.N, n_inner=at.n_inner, n_outer=at.n_outer, n_act=dmt.nAct, n_valid_act=dmt.nValidAct,
-                   dm_separable=1, wfs_type=L.WFS_SH, n_subap=p.nSubaperture, n_valid_subap=sht.nValid,
-                   n_signal=sht.nSignal, cam_res=sht.cam_res, n_loop=int(p.nLoop), max_group=max_group,
+                   dm_separable=1, n_subap=p.nSubaperture, n_valid_subap=len(valid_idx), n_signal=2 * len(valid_idx),
+                   cam_res=self.cam_res, n_loop=int(p.nLoop), max_group=max_group,
                    atm_wavelength=calib.ATM_WAVELENGTH, src_wavelength=self.src_wavelength, leak=p.leak,
                    threshold_cog=p.threshold_cog)
+        if self.wfs_type == "sh":
+            cfg.update(wfs_type=L.WFS_SH)
+        else:
+            pt = self._pyr_tables
+            cfg.update(wfs_type=L.WFS_PYRAMID, pyr_n_res=pt.nRes, pyr_n_theta=self._wfs_n_theta,
+                       pyr_centering=int(pt.psf_centering), pyr_norm_valid=pt.norm_valid, pyr_q_lo=pt.q_lo, pyr_q_hi=pt.q_hi)
         sh = Shard(cfg, self.device_index)
         sh.upload(L.C_PUPIL, self.pupil.astype(np.uint8))
         sh.upload(L.C_DM_GX, dmt.gx)
         sh.upload(L.C_DM_GY, dmt.gy)
         sh.upload(L.C_ACT_IDX, dmt.act_idx)
-        sh.upload(L.C_WFS_AMP, sht.amp)
-        sh.upload(L.C_SH_SUBAP_IDX, sht.subap_idx)
+        sh.upload(L.C_SH_SUBAP_IDX, valid_idx)
+        if self.wfs_type == "sh":
+            sh.upload(L.C_WFS_AMP, self._sh_tables.amp)
+        else:
+            sh.upload(L.C_WFS_AMP, self._pyr_tables.amplitude(self._wfs_n_theta))
+            sh.upload(L.C_PYR_MASK, self._pyr_tables.mask_pairs)
+            if self._wfs_n_theta > 1:
+                sh.upload(L.C_PYR_TT, self._pyr_tt)
         return sh
+
+    def _calibrate_pyramid(self):
+        """Pyramid initialisation (OOPAO/Pyramid.py:306-314, 408-466): valid pixels from the flux at the (large)
+        calibration modulation, then the reference slopes of a flat wave-front at the user modulation.  Both are
+        measured by the HIP kernels in float64.  Returns (reference at the valid pixels, slopesUnits = 1)."""
+        p, pt, R = self.param, self._pyr_tables, self.R
+        ns = p.nSubaperture
+        # 1. flux at calibModulation, all quadrant pixels provisionally valid
+        self._wfs_valid_idx = np.arange(ns * ns, dtype=np.int32)
+        self._wfs_n_theta, self._pyr_tt = pt.modulation_table(pt.calib_modulation)
+        cal = self._make_shard(1, "f64", n_layer=0, max_group=1)
+        try:
+            cal.upload(L.C_SH_REF, np.zeros(2 * ns * ns))
+            cal.upload(L.C_WFS_UNITS, np.array([1.0]))
+            cal.measure()
+            frame = cal.download(L.B_FRAME, (1, self.cam_res, self.cam_res))[0].astype(np.float64)
+        finally:
+            cal.close()
+        i4q = pt.quadrant_sum(frame)
+        light = 0.1 if p.lightThreshold is None else p.lightThreshold
+        self.validI4Q = i4q >= light * i4q.max()
+        self._wfs_valid_idx = np.flatnonzero(self.validI4Q.reshape(-1)).astype(np.int32)
+        self.nSignal = 2 * len(self._wfs_valid_idx)
+        # 2. reference slopes: OPD = 1 m of piston inside the pupil (wfs_calibration), user modulation
+        self._wfs_n_theta, self._pyr_tt = pt.modulation_table(p.modulation)
+        cal = self._make_shard(1, "f64", n_layer=0, max_group=1)
+        try:
+            cal.upload(L.C_SH_REF, np.zeros(self.nSignal))
+            cal.upload(L.C_WFS_UNITS, np.array([1.0]))
+            cal.set_atm_opd(np.ones((1, R * R)))
+            cal.measure()
+            ref = cal.download(L.B_SIGNAL, (1, self.nSignal))[0].astype(np.float64)
+        finally:
+            cal.close()
+        return ref, 1.0
 
     def _calibrate_wfs(self):
         """initialize_wfs (OOPAO/ShackHartmann.py:254-312): reference centroids from a flat wave-front,
         slope units from a five-point tip ramp, measured by the HIP kernels in float64."""
         R, nv = self.R, self._sh_tables.nValid
+        self.nSignal = 2 * nv
         cal = self._make_shard(5, "f64", n_layer=0, max_group=1)
         try:
             cal.upload(L.C_SH_REF, np.zeros(2 * nv))
@@ -448,15 +512,23 @@ class BatchedAOEnv:
         centroid threshold as the reference's batched measurement does."""
         A_ = self.nValidAct
         stroke = self.src_wavelength / 16
-        cal = self._make_shard(A_, "f64", n_layer=0, max_group=int(self.param.nMeasurements))
-        try:
-            cal.upload(L.C_SH_REF, ref)
-            cal.upload(L.C_WFS_UNITS, np.array([units]))
-            cal.set_coefs(np.eye(A_) * stroke)
-            cal.measure()
-            sig = cal.download(L.B_SIGNAL, (A_, self.nSignal)).astype(np.float64)
-        finally:
-            cal.close()
+        n_meas = int(self.param.nMeasurements)
+        # pokes per calibration shard: whole measurement groups, bounded so that the Pyramid's nRes^2 scratch fits
+        batch = A_ if self.wfs_type == "sh" else max(n_meas, (96 // n_meas) * n_meas)
+        sig = np.zeros((A_, self.nSignal))
+        for a0 in range(0, A_, batch):
+            n = min(batch, A_ - a0)
+            cal = self._make_shard(n, "f64", n_layer=0, max_group=n_meas)
+            try:
+                cal.upload(L.C_SH_REF, ref)
+                cal.upload(L.C_WFS_UNITS, np.array([units]))
+                coefs = np.zeros((n, A_))
+                coefs[np.arange(n), a0 + np.arange(n)] = stroke
+                cal.set_coefs(coefs)
+                cal.measure()
+                sig[a0:a0 + n] = cal.download(L.B_SIGNAL, (n, self.nSignal)).astype(np.float64)
+            finally:
+                cal.close()
         return (sig / stroke).T                                     # [nSignal, A]
 
     # -- plumbing ---------------------------------------------------------------------------------------

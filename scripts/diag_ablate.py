@@ -6,7 +6,7 @@ from rlao_amd import _lib as L
 import bench
 N = int(sys.argv[1])
 env = BatchedAOEnv(n_envs=N, device=0, dtype="f32")
-env.set_params(dict(bench.GEOMETRY, nLoop=6000))
+env.set_params(dict(bench.GEOMETRY, nLoop=6000), wfs_type="shackhartmann")
 env.generate_new_phase_screen(17); env.dm.coefs = 0; env.measure(); env.reset_soft()
 env.run_integrator(0, 20); torch.cuda.synchronize()
 i0 = 20

@@ -5,7 +5,7 @@ from rlao_amd.env import BatchedAOEnv
 import bench
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 env = BatchedAOEnv(n_envs=N, device=0, dtype="f32")
-env.set_params(dict(bench.GEOMETRY, nLoop=5000))
+env.set_params(dict(bench.GEOMETRY, nLoop=5000), wfs_type="shackhartmann")
 env.generate_new_phase_screen(17); env.dm.coefs = 0; env.measure(); env.reset_soft()
 env.run_integrator(0, 20); torch.cuda.synchronize()
 for mode in ("single_call", "per_step"):

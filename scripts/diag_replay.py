@@ -11,8 +11,11 @@ prm = dict(diameter=float(g["cfg_D"]), nSubaperture=int(g["cfg_nsub"]), nPixelPe
            r0=float(g["cfg_r0"]), L0=float(g["cfg_L0"]), windSpeed=list(g["cfg_ws"]), windDirection=list(g["cfg_wd"]),
            fractionnalR0=list(g["cfg_frac"]), altitude=list(g["cfg_alt"]), nModes=int(g["cfg_n_modes"]), nLoop=64)
 env = BatchedAOEnv(n_envs=len(seeds), device=0, dtype=dtype)
-env.set_params(prm, m2c=g["m2c"])
-print("units", env.slopes_units, float(g["slopes_units"]), "imat relerr", np.abs(env.imat - g["imat"]).max() / np.abs(g["imat"]).max(),
+pyr = "cfg_wfs" in g
+if pyr:
+    prm.update(modulation=float(g["cfg_modulation"]), psfCentering=bool(g["cfg_centering"]))
+env.set_params(prm, wfs_type="pyramid" if pyr else "shackhartmann", m2c=g["m2c"])
+print("units", env.slopes_units, float(g["slopes_units"]) if "slopes_units" in g else 1.0, "imat relerr", np.abs(env.imat - g["imat"]).max() / np.abs(g["imat"]).max(),
       "recon relerr", np.abs(env.reconstructor - g["recon"]).max() / np.abs(g["recon"]).max())
 env.env_seed_stride = (seeds[1] - seeds[0]) if len(seeds) > 1 else 1
 env.generate_new_phase_screen(seeds[0])

@@ -37,7 +37,7 @@ def test_switches_agree_small():
     for opts in [dict(), {L.OPT_FAST_WFS: 0}, {L.OPT_MFMA_GEMM: 0}, {L.OPT_FAST_TRIG: 0},
                  {L.OPT_FAST_WFS: 0, L.OPT_MFMA_GEMM: 0, L.OPT_FAST_TRIG: 0}]:
         env = BatchedAOEnv(n_envs=3, device=0, dtype="f32")
-        env.set_params(SMALL)
+        env.set_params(SMALL, wfs_type="shackhartmann")
         for k, v in opts.items():
             L.check(env._shard.lib.aoenv_set_option(env._shard.h, k, v))
         out = _run(env, 12, 5)
@@ -58,7 +58,7 @@ def test_full_size_batch_invariance_and_determinism():
     import torch
     from rlao_amd.env import BatchedAOEnv
     env = BatchedAOEnv(n_envs=256, device=0, dtype="f32", env_seed_stride=0)     # every env: seed 17
-    env.set_params(C2)
+    env.set_params(C2, wfs_type="shackhartmann")
     a = _run(env, 8, 17)
     b = _run(env, 8, 17)
     for (o, f, r, s), (o2, f2, r2, s2) in zip(a, b):
@@ -78,7 +78,7 @@ def test_run_integrator_equals_stepping():
     import torch
     from rlao_amd.env import BatchedAOEnv
     env = BatchedAOEnv(n_envs=4, device=0, dtype="f32")
-    env.set_params(SMALL, gainCL=0.4)
+    env.set_params(SMALL, wfs_type="shackhartmann", gainCL=0.4)
     a = _run(env, 10, 3, gain=0.4)
     env.generate_new_phase_screen(3)
     env.dm.coefs = 0
@@ -98,7 +98,7 @@ def test_random_actions_match_oracle_c2():
     from oracle import ao_oracle as O
     from rlao_amd.env import BatchedAOEnv
     env = BatchedAOEnv(n_envs=3, device=0, dtype="f32", env_seed_stride=100)
-    env.set_params(C2)
+    env.set_params(C2, wfs_type="shackhartmann")
     env.generate_new_phase_screen(23)
     env.dm.coefs = 0
     env.measure()
@@ -133,7 +133,7 @@ def test_single_env_flavour_returns_reference_types(golden_dir):
     g = np.load(os.path.join(golden_dir, "small_sh.npz"))
     env = OOPAO(device=0, dtype="f64")
     env.set_params_file("Conf.parameterFile_oopao_parser", "AO_OOPAO")
-    env.set_params(SMALL, m2c=g["m2c"])
+    env.set_params(SMALL, wfs_type="shackhartmann", m2c=g["m2c"])
     env.atm.generateNewPhaseScreen(17)
     env.dm.coefs = 0
     env.tel * env.dm * env.wfs
@@ -174,7 +174,7 @@ def test_c_abi_reports_errors():
     from rlao_amd.env import BatchedAOEnv
     lib = L.load()
     env = BatchedAOEnv(n_envs=2, device=0, dtype="f32")
-    env.set_params(SMALL)
+    env.set_params(SMALL, wfs_type="shackhartmann")
     h = env._shard.h
     assert lib.aoenv_step(h, 10 ** 6, C.c_void_p(env._obs.data_ptr()), C.c_void_p(env._obs.data_ptr()), None, None, None, None) != 0
     assert b"frame index" in lib.aoenv_last_error()
