@@ -19,7 +19,8 @@ def test_params_accept_both_reference_spellings():
     b = calib.params_from_args(dict(r0=0.1, L0=25, fractionalR0=[0.7, 0.3], windSpeed=[5, 6], windDirection=[0, 90],
                                     altitude=[0, 0], nLoop=100, gainCL=0.3))
     assert a.fractionalR0 == b.fractionalR0 == [0.7, 0.3] and a.nLayer == 2
-    assert a.resolution == 120 and a.nActuator == 21 and a.extra == {"modulation": 0}
+    assert a.resolution == 120 and a.nActuator == 21 and a.modulation == 0 and a.extra == {}
+    assert calib.params_from_args(dict(savedir="x")).extra == {"savedir": "x"}
     with pytest.raises(ValueError):
         calib.params_from_args(dict(fractionalR0=[1.0], windSpeed=[1.0, 2.0]))
 
