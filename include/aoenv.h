@@ -90,6 +90,8 @@ enum AoConst {
     AOENV_C_RECON,           /* [f64 A*n_signal] reconstructor = M2C @ calib.M (MAIN/OOPAOEnv/OOPAOEnv.py:381) */
     AOENV_C_PYR_MASK,        /* [f64 nRes*nRes*2] exp(i m) of the pyramid mask, rounded to complex64 (OOPAO/Pyramid.py:323) */
     AOENV_C_PYR_TT,          /* [f64 n_theta*R*R] modulation tip/tilt phases, float32-rounded (OOPAO/Pyramid.py:964-970) */
+    AOENV_C_RECON_FACTORS,   /* [f64 K*n_signal + A*K] optional: calib.M (K x nSig) then M2C (A x K) with reconstructor = M2C @ M
+                                (MAIN/OOPAOEnv/OOPAOEnv.py:295, 381); enables the fused low-rank tail.  Upload after AOENV_C_RECON */
     AOENV_C_COUNT
 };
 
@@ -188,6 +190,8 @@ enum AoOption {
     AOENV_OPT_MFMA_GEMM = 1, /* 1 (default): float32 split-K MFMA contractions; 0: generic tiled VALU kernel */
     AOENV_OPT_STORE_ATM_OPD = 3, /* 1: every step also writes atm.OPD_no_pupil to AOENV_B_OPD_ATM; 0 (default): it is
                                 re-derived from the screens when it is downloaded */
+    AOENV_OPT_FUSED_TAIL = 4, /* 1 (default): when AOENV_C_RECON_FACTORS is uploaded, SH centroid + low-rank R.s + epilogue run as
+                                 one per-env kernel; 0: separate centroid / MFMA GEMM / epilogue kernels */
     AOENV_OPT_FAST_TRIG = 2  /* 1 (default): v_sin/v_cos after Cody-Waite reduction in the float32 SH kernel; 0: sincosf */
 };
 int aoenv_set_option(AoEnv* env, int option, int value);
@@ -198,7 +202,7 @@ int aoenv_set_option(AoEnv* env, int option, int value);
  * AoKernel.  aoenv_profile(env, 0|1) also clears the recorded events. */
 enum AoKernel {
     AOENV_K_SHIFT_GATHER = 0, AOENV_K_MT_NORMAL, AOENV_K_GEMM_RING, AOENV_K_SCATTER, AOENV_K_PHASE,
-    AOENV_K_SH_SPOTS, AOENV_K_SH_CENTROID, AOENV_K_GEMM_RECON, AOENV_K_RECON_FINISH, AOENV_K_PYRAMID, AOENV_K_COUNT
+    AOENV_K_SH_SPOTS, AOENV_K_SH_CENTROID, AOENV_K_GEMM_RECON, AOENV_K_RECON_FINISH, AOENV_K_PYRAMID, AOENV_K_SH_TAIL, AOENV_K_COUNT
 };
 int aoenv_profile(AoEnv* env, int enable);
 int aoenv_profile_read(AoEnv* env, double* h_ms, int32_t* h_count, void* stream);

@@ -431,7 +431,9 @@ def svd_inverse(D: np.ndarray) -> np.ndarray:
     return Vt.T @ np.diag(1 / s) @ U.T
 
 
-def reconstructor_from_imat(imat: np.ndarray, m2c: np.ndarray):
-    """(reconstructor, F) of MAIN/OOPAOEnv/OOPAOEnv.py:295, 381-383."""
+def reconstructor_from_imat(imat: np.ndarray, m2c: np.ndarray, return_factors: bool = False):
+    """(reconstructor, F) of MAIN/OOPAOEnv/OOPAOEnv.py:295, 381-383 [+ the modal command matrix calib.M]."""
     M = svd_inverse(imat @ m2c)
+    if return_factors:
+        return m2c @ M, m2c @ np.linalg.pinv(m2c), M
     return m2c @ M, m2c @ np.linalg.pinv(m2c)

@@ -15,6 +15,7 @@ constexpr int kWave = 64;          // CDNA wavefront
 constexpr int kMaxLayer = 8;
 constexpr int kMtN = 624;          // MT19937 state words
 constexpr int kMaxSplits = 16;     // split-K slabs of the float32 MFMA GEMM
+constexpr int kMaxModes = 512;     // rank of the factored reconstructor (fused tail)
 
 int fail(const char* fmt, ...);
 #define AO_HIP(call)                                                                          \
@@ -136,6 +137,11 @@ struct FinishArgs {
 };
 template <typename T>
 int launch_recon_finish(const FinishArgs<T>& fa, int n_env, hipStream_t st);
+// fused SH tail: centroid + low-rank R.s + epilogue in one launch; -1 if it does not fit in LDS
+template <typename T>
+int launch_sh_tail(const T* frame, const T* wfs_max, const ShConst<T>& sc, T* signal, const T* fac_m,
+                   const T* fac_m2c_t, int n_modes, const FinishArgs<T>& fa, int n_env, int R, int n_subap, int n_valid,
+                   int max_group, hipStream_t st);
 template <typename T>
 int launch_convert_from_f64(const double* src, T* dst, size_t n, hipStream_t st);
 

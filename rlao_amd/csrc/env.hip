@@ -76,6 +76,9 @@ struct AoEnv {
     void* frame = nullptr;
     void* signal = nullptr;
     void* recon = nullptr;                  // [A][nSig]
+    void* fac_m = nullptr;                  // [K][nSig] modal command matrix calib.M          (AOENV_C_RECON_FACTORS)
+    void* fac_m2c_t = nullptr;              // [K][A]    transposed M2C
+    int n_modes = 0;
     // Pyramid
     void* pyr_mask = nullptr;               // [N*N][2]
     void* pyr_tt = nullptr;                 // [nTheta][R*R]
@@ -91,6 +94,7 @@ struct AoEnv {
     bool use_fast_wfs = true;               // aoenv_set_option(AOENV_OPT_FAST_WFS)
     bool use_mfma = true;                   // aoenv_set_option(AOENV_OPT_MFMA_GEMM)
     bool use_fast_trig = true;              // aoenv_set_option(AOENV_OPT_FAST_TRIG)
+    bool use_fused_tail = true;             // aoenv_set_option(AOENV_OPT_FUSED_TAIL); needs AOENV_C_RECON_FACTORS
     bool store_opd_atm = false;             // aoenv_set_option(AOENV_OPT_STORE_ATM_OPD): write atm.OPD every step
     bool atm_user_defined = false;          // aoenv_set_atm_opd() until the next step / new screens
     int debug_ablate = 0;                   // aoenv_set_option(99): skip kernel sections (timing diagnosis only)
@@ -344,6 +348,34 @@ int refresh_dense_dm(AoEnv* env, hipStream_t st) {
 }
 
 template <typename T>
+FinishArgs<T> finish_args(AoEnv* env, const T* d_action, T* d_obs, T* d_reward, T* d_strehl, int telemetry_index,
+                          int integrate, double gain, int splits) {
+    FinishArgs<T> fa{};
+    fa.v = env->as<T>(env->vbuf);
+    fa.splits = splits;
+    fa.act_idx = env->act_idx;
+    fa.action = d_action;
+    fa.coefs = env->as<T>(env->coefs);
+    fa.obs = d_obs;
+    fa.reward = d_reward;
+    fa.strehl = d_strehl;
+    fa.scal = env->as<T>(env->scal);
+    fa.total = env->as<T>(env->total);
+    fa.residual = env->as<T>(env->residual);
+    fa.part = env->part;
+    fa.n_tiles = env->n_tiles;
+    fa.n_pupil = env->n_pupil;
+    fa.telemetry_index = telemetry_index;
+    fa.n_act = env->nAct;
+    fa.n_valid_act = env->A;
+    fa.do_integrate = integrate;
+    fa.leak = (T)env->c.leak;
+    fa.gain_from_obs = (T)gain;
+    fa.src_scale = 6.283185307179586476925286766559 / env->c.src_wavelength;
+    return fa;
+}
+
+template <typename T>
 int run_recon(AoEnv* env, const T* d_action, T* d_obs, T* d_reward, T* d_strehl, int telemetry_index, int integrate,
               double gain, hipStream_t st) {
     int splits = 1;
@@ -353,28 +385,7 @@ int run_recon(AoEnv* env, const T* d_action, T* d_obs, T* d_reward, T* d_strehl,
                                 env->A, env->nSig, &splits, st));
     }
     {
-        FinishArgs<T> fa{};
-        fa.v = env->as<T>(env->vbuf);
-        fa.splits = splits;
-        fa.act_idx = env->act_idx;
-        fa.action = d_action;
-        fa.coefs = env->as<T>(env->coefs);
-        fa.obs = d_obs;
-        fa.reward = d_reward;
-        fa.strehl = d_strehl;
-        fa.scal = env->as<T>(env->scal);
-        fa.total = env->as<T>(env->total);
-        fa.residual = env->as<T>(env->residual);
-        fa.part = env->part;
-        fa.n_tiles = env->n_tiles;
-        fa.n_pupil = env->n_pupil;
-        fa.telemetry_index = telemetry_index;
-        fa.n_act = env->nAct;
-        fa.n_valid_act = env->A;
-        fa.do_integrate = integrate;
-        fa.leak = (T)env->c.leak;
-        fa.gain_from_obs = (T)gain;
-        fa.src_scale = 6.283185307179586476925286766559 / env->c.src_wavelength;
+        FinishArgs<T> fa = finish_args<T>(env, d_action, d_obs, d_reward, d_strehl, telemetry_index, integrate, gain, splits);
         AO_PROF(env, RECON_FINISH, st);
         AO_TRY(launch_recon_finish<T>(fa, env->E, st));
     }
@@ -388,9 +399,42 @@ int step_t(AoEnv* env, int i, const void* d_action, void* d_obs, void* d_frame, 
     AO_TRY(advance_atmosphere<T>(env, st));
     env->atm_user_defined = false;
     AO_TRY(run_phase<T>(env, 1, env->store_opd_atm ? 1 : 0, st));
-    AO_TRY(run_wfs<T>(env, st));
-    AO_TRY(run_recon<T>(env, static_cast<const T*>(d_action), static_cast<T*>(d_obs), static_cast<T*>(d_reward),
-                        static_cast<T*>(d_strehl), i, 1, gain, st));
+    // one workgroup per env re-reads the factors from L2: wins while launch latency dominates (measured: 19.5 us vs
+    // 32.5 us at 256 envs, 96 us vs 75 us at 2048), the batched MFMA GEMM path takes over for large shards
+    const bool fused = env->c.wfs_type == AOENV_WFS_SH && env->use_fused_tail && env->n_modes > 0 && env->E <= 1024;
+    if (fused) {
+        const ShConst<T> sc = sh_const<T>(env);
+        {
+            AO_PROF(env, SH_SPOTS, st);
+            AO_TRY(launch_sh_spots<T>(env->as<T>(env->phase), sc, env->as<T>(env->frame), env->as<T>(env->wfs_max), env->E,
+                                      env->R, env->nSub, env->nVal, st));
+        }
+        FinishArgs<T> fa = finish_args<T>(env, static_cast<const T*>(d_action), static_cast<T*>(d_obs),
+                                          static_cast<T*>(d_reward), static_cast<T*>(d_strehl), i, 1, gain, 1);
+        int rc;
+        {
+            AO_PROF(env, SH_TAIL, st);
+            rc = launch_sh_tail<T>(env->as<T>(env->frame), env->as<T>(env->wfs_max), sc, env->as<T>(env->signal),
+                                   env->as<T>(env->fac_m), env->as<T>(env->fac_m2c_t), env->n_modes, fa, env->E, env->R,
+                                   env->nSub, env->nVal, env->c.max_group, st);
+        }
+        if (rc > 0) return rc;
+        if (rc == 0) {
+            AO_TRY(refresh_dense_dm<T>(env, st));
+        } else {                                                   // does not fit in LDS: the separate kernels
+            {
+                AO_PROF(env, SH_CENTROID, st);
+                AO_TRY(launch_sh_centroid<T>(env->as<T>(env->frame), env->as<T>(env->wfs_max), sc, env->as<T>(env->signal),
+                                             env->E, env->R, env->nSub, env->nVal, env->c.max_group, st));
+            }
+            AO_TRY(run_recon<T>(env, static_cast<const T*>(d_action), static_cast<T*>(d_obs), static_cast<T*>(d_reward),
+                                static_cast<T*>(d_strehl), i, 1, gain, st));
+        }
+    } else {
+        AO_TRY(run_wfs<T>(env, st));
+        AO_TRY(run_recon<T>(env, static_cast<const T*>(d_action), static_cast<T*>(d_obs), static_cast<T*>(d_reward),
+                            static_cast<T*>(d_strehl), i, 1, gain, st));
+    }
     if (d_frame)
         AO_HIP(hipMemcpyAsync(d_frame, env->frame, (size_t)env->E * env->c.cam_res * env->c.cam_res * sizeof(T),
                               hipMemcpyDeviceToDevice, st));
@@ -510,6 +554,8 @@ int aoenv_create(const AoCfg* cfg, int device, AoEnv** out) {
     A_(&e->frame, E * (size_t)cfg->cam_res * cfg->cam_res * z);
     A_(&e->signal, E * e->nSig * z);
     A_(&e->recon, (size_t)e->A * e->nSig * z);
+    A_(&e->fac_m, (size_t)kMaxModes * e->nSig * z);
+    A_(&e->fac_m2c_t, (size_t)kMaxModes * e->A * z);
     if (cfg->wfs_type == AOENV_WFS_PYRAMID) {
         const size_t N = cfg->pyr_n_res;
         e->pyr_chunk = cfg->pyr_n_theta < 4 ? cfg->pyr_n_theta : 4;
@@ -652,7 +698,23 @@ int aoenv_upload(AoEnv* env, int kind, const void* h, size_t bytes) {
         case AOENV_C_RECON:
             AO_TRY(need((size_t)env->A * env->nSig * 8));
             AO_TRY(upload_real(env, env->recon, d, (size_t)env->A * env->nSig));
+            env->n_modes = 0;                                      // factors must be re-uploaded for a new R
             break;
+        case AOENV_C_RECON_FACTORS: {
+            // [K*nSig] M then [A*K] M2C, K from the size
+            const size_t per = (size_t)env->nSig + env->A;
+            if (bytes % (8 * per)) return fail("aoenv_upload(RECON_FACTORS): %zu bytes is not K*(nSig+A) doubles", bytes);
+            const int K = (int)(bytes / (8 * per));
+            if (K < 1 || K > kMaxModes) return fail("reconstructor rank %d outside [1, %d]", K, kMaxModes);
+            AO_TRY(upload_real(env, env->fac_m, d, (size_t)K * env->nSig));
+            const double* m2c = d + (size_t)K * env->nSig;
+            std::vector<double> t((size_t)K * env->A);
+            for (int a = 0; a < env->A; ++a)
+                for (int k = 0; k < K; ++k) t[(size_t)k * env->A + a] = m2c[(size_t)a * K + k];
+            AO_TRY(upload_real(env, env->fac_m2c_t, t.data(), t.size()));
+            env->n_modes = K;
+            break;
+        }
         case AOENV_C_PYR_MASK: {
             if (env->c.wfs_type != AOENV_WFS_PYRAMID) return fail("not a pyramid shard");
             const size_t n = (size_t)env->c.pyr_n_res * env->c.pyr_n_res * 2;
@@ -868,6 +930,7 @@ int aoenv_set_option(AoEnv* env, int option, int value) {
         case AOENV_OPT_MFMA_GEMM: env->use_mfma = value != 0; return 0;
         case AOENV_OPT_FAST_TRIG: env->use_fast_trig = value != 0; return 0;
         case AOENV_OPT_STORE_ATM_OPD: env->store_opd_atm = value != 0; return 0;
+        case AOENV_OPT_FUSED_TAIL: env->use_fused_tail = value != 0; return 0;
         case 99: env->debug_ablate = value; return 0;
         default: return fail("unknown option %d", option);
     }

@@ -373,10 +373,157 @@ int launch_sh_centroid(const T* frame, const T* wfs_max, const ShConst<T>& sc, T
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Fused tail: centre of gravity -> obs = -R s -> reward, integrator and telemetry in ONE launch, one workgroup
+// (1024 lanes) per env.  The three separate kernels (centroid, split-K GEMM, epilogue) are mostly launch + memory
+// latency (~10 us each for < 1 us of work at a few hundred envs).  The reconstructor is low rank by construction,
+// R = M2C (A x K) . M (K x nSig) with K = nModes = 50 (MAIN/OOPAOEnv/OOPAOEnv.py:295, 381), so a per-env product
+// through the factors costs 4.5x fewer MACs than R s and re-reads 0.2 MB instead of 0.9 MB from L2 per env:
+//   t = M s   : 16 lanes per mode, contiguous reads of the mode's row, DPP fold
+//   o = M2C t : one lane per actuator, M2C stored transposed [K][A] (coalesced), t in LDS
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(1024) k_sh_tail(const T* __restrict__ frame, const T* __restrict__ wfs_max,
+                                                   const ShConst<T> sc, T* __restrict__ signal,
+                                                   const T* __restrict__ fac_m, const T* __restrict__ fac_m2c_t,
+                                                   int n_modes, const FinishArgs<T> f, int R, int n_subap,
+                                                   int n_valid, int max_group, int n_env) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    T* sl = reinterpret_cast<T*>(lds_raw);                     // [2 nValid] slopes
+    T* img_s = sl + 2 * n_valid;                               // [nAct^2] observation image
+    __shared__ double red[16];
+    const int e = blockIdx.x, tid = threadIdx.x;
+    const int p = R / n_subap;
+    const int g0 = (e / max_group) * max_group, g1 = min(g0 + max_group, n_env);
+    T mx = 0;
+    for (int q = g0; q < g1; ++q) mx = wfs_max[q] > mx ? wfs_max[q] : mx;
+    const T cut = sc.threshold * mx;
+    const T* fr = frame + (size_t)e * R * R;
+    const int img = f.n_act * f.n_act;
+    for (int q = tid; q < img; q += blockDim.x) img_s[q] = (T)0;
+    // ---- centroids: 2 lanes per lenslet (p/2 camera rows each) ----------------------------------------------------
+    for (int w = tid; w < 2 * n_valid; w += blockDim.x) {
+        const int s = w >> 1, half = w & 1;
+        const int k = sc.subap_idx[s], i = k / n_subap, j = k % n_subap;
+        T norm = 0, m0 = 0, m1 = 0;
+        for (int u = half; u < p; u += 2) {
+            const T* row = fr + (size_t)(i * p + u) * R + j * p;
+            T rs = 0, rm = 0;
+            for (int v = 0; v < p; ++v) {
+                T x = row[v];
+                x = x < cut ? (T)0 : x;
+                rs += x;
+                rm += x * (T)v;
+            }
+            norm += rs;
+            m0 += rs * (T)u;
+            m1 += rm;
+        }
+        norm += __shfl_xor(norm, 1);
+        m0 += __shfl_xor(m0, 1);
+        m1 += __shfl_xor(m1, 1);
+        if (half == 0) {
+            T c0 = (T)0, c1 = (T)0;
+            if (norm != (T)0) {
+                c0 = m0 / norm;
+                c1 = m1 / norm;
+            }
+            const T s0 = (c0 - sc.ref[s]) / sc.units, s1 = (c1 - sc.ref[n_valid + s]) / sc.units;
+            sl[s] = s0;
+            sl[n_valid + s] = s1;
+            signal[(size_t)e * 2 * n_valid + s] = s0;
+            signal[(size_t)e * 2 * n_valid + n_valid + s] = s1;
+        }
+    }
+    __syncthreads();
+    // ---- t = M s -------------------------------------------------------------------------------------------------------
+    const int n_sig = 2 * n_valid, A = f.n_valid_act;
+    T* tm = img_s + img;                                        // [K] modal coefficients
+    for (int k0 = 0; k0 < n_modes; k0 += (int)blockDim.x / 16) {
+        const int k = k0 + tid / 16, l16 = tid & 15;
+        T acc = 0;
+        if (k < n_modes) {
+            const T* row = fac_m + (size_t)k * n_sig;
+#pragma unroll 4
+            for (int q = l16; q < n_sig; q += 16) acc += row[q] * sl[q];
+        }
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 16);
+        if (k < n_modes && l16 == 0) tm[k] = acc;
+    }
+    __syncthreads();
+    // ---- o = -M2C t, integrator, image ---------------------------------------------------------------------------------
+    double ss = 0.0;
+    for (int k = tid; k < A; k += blockDim.x) {
+        T acc = 0;
+        const T* col = fac_m2c_t + k;
+#pragma unroll 10
+        for (int q = 0; q < n_modes; ++q) acc += col[(size_t)q * A] * tm[q];
+        const int px = f.act_idx[k];
+        T* ob = f.obs + (size_t)e * img;
+        if (f.do_integrate) {
+            const T act = (f.gain_from_obs != (T)0) ? f.gain_from_obs * ob[px] : f.action[(size_t)e * img + px];
+            T* c = f.coefs + (size_t)e * A + k;
+            const float af = (float)act;                          // float32 increment, see k_recon_finish
+            const T inc = ((T)af == act) ? (T)(af * 1e-6f) : act * (T)1e-6;
+            *c = (*c) * f.leak + inc;
+        }
+        const T o = -acc * (T)1e6;
+        img_s[px] = o;
+        ss += (double)o * (double)o;
+    }
+    __syncthreads();
+    T* ob = f.obs + (size_t)e * img;
+    for (int q = tid; q < img; q += blockDim.x) ob[q] = img_s[q];
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off);
+    if ((tid & (kWave - 1)) == 0) red[tid / kWave] = ss;
+    __syncthreads();
+    if (tid == 0) {
+        double tot = 0;
+        for (int q = 0; q < (int)blockDim.x / kWave; ++q) tot += red[q];
+        if (f.reward) f.reward[e] = (T)(-sqrt(tot));
+        double v[4] = {0, 0, 0, 0};
+        const double* pp = f.part + (size_t)e * f.n_tiles * 4;
+        for (int t = 0; t < f.n_tiles; ++t)
+            for (int k = 0; k < 4; ++k) v[k] += pp[t * 4 + k];
+        const double n = (double)f.n_pupil;
+        double var_atm = v[1] / n - (v[0] / n) * (v[0] / n);
+        double var_res = v[3] / n - (v[2] / n) * (v[2] / n);
+        var_atm = var_atm > 0 ? var_atm : 0;
+        var_res = var_res > 0 ? var_res : 0;
+        const double total = sqrt(var_atm) * 1e9, resid = sqrt(var_res) * 1e9;
+        const double sr = exp(-var_res * f.src_scale * f.src_scale);
+        T* scp = f.scal + 4 * e;
+        scp[0] = (T)total;
+        scp[1] = (T)resid;
+        scp[2] = (T)sr;
+        if (f.strehl) f.strehl[e] = (T)sr;
+        if (f.telemetry_index >= 0) {
+            const size_t o = (size_t)f.telemetry_index * n_env + e;
+            f.total[o] = (T)total;
+            f.residual[o] = (T)resid;
+        }
+    }
+}
+
+template <typename T>
+int launch_sh_tail(const T* frame, const T* wfs_max, const ShConst<T>& sc, T* signal, const T* fac_m,
+                   const T* fac_m2c_t, int n_modes, const FinishArgs<T>& fa, int n_env, int R, int n_subap, int n_valid,
+                   int max_group, hipStream_t st) {
+    const size_t lds = sizeof(T) * ((size_t)2 * n_valid + (size_t)fa.n_act * fa.n_act + (size_t)n_modes);
+    if (lds > 64 * 1024) return -1;
+    hipLaunchKernelGGL(k_sh_tail<T>, dim3(n_env), dim3(1024), lds, st, frame, wfs_max, sc, signal, fac_m, fac_m2c_t,
+                       n_modes, fa, R, n_subap, n_valid, max_group, n_env);
+    AO_HIP(hipGetLastError());
+    return 0;
+}
+
 #define INST(T)                                                                                                 \
     template int launch_sh_spots<T>(const T*, const ShConst<T>&, T*, T*, int, int, int, int, hipStream_t);      \
     template int launch_sh_centroid<T>(const T*, const T*, const ShConst<T>&, T*, int, int, int, int, int,      \
-                                       hipStream_t);
+                                       hipStream_t);                                                            \
+    template int launch_sh_tail<T>(const T*, const T*, const ShConst<T>&, T*, const T*, const T*, int,         \
+                                   const FinishArgs<T>&, int, int, int, int, int, hipStream_t);
 INST(float)
 INST(double)
 #undef INST

@@ -387,7 +387,7 @@ class BatchedAOEnv:
         self.M2C_CL = np.asarray(m2c, dtype=np.float64)[:, :p.nModes]
         if self.M2C_CL.shape[0] != self.nValidAct:
             raise ValueError(f"M2C has {self.M2C_CL.shape[0]} rows, the DM has {self.nValidAct} valid actuators")
-        self.reconstructor, self.F = calib.reconstructor_from_imat(self.imat, self.M2C_CL)
+        self.reconstructor, self.F, self.modal_CM = calib.reconstructor_from_imat(self.imat, self.M2C_CL, True)
         self._F_t = torch.as_tensor(self.F, device=self.device, dtype=self.tdtype)
 
         # -- the loop shard -----------------------------------------------------------------------------
@@ -401,6 +401,7 @@ class BatchedAOEnv:
         sh.upload(L.C_SH_REF, ref)
         sh.upload(L.C_WFS_UNITS, np.array([units]))
         sh.upload(L.C_RECON, self.reconstructor)
+        sh.upload(L.C_RECON_FACTORS, np.concatenate([self.modal_CM.reshape(-1), self.M2C_CL.reshape(-1)]))
         self._push_wind(reset=True)
         N, A_ = self.n_envs, self.nActuator
         self._obs = torch.zeros((N, A_, A_), device=self.device, dtype=self.tdtype)

@@ -47,9 +47,9 @@ def test_cfg_layout_and_enums_match_header(built_lib, tmp_path):
     enums = ["AOENV_F32", "AOENV_F64", "AOENV_WFS_SH", "AOENV_C_PUPIL", "AOENV_C_AB", "AOENV_C_INNER_IDX",
              "AOENV_C_OUTER_IDX", "AOENV_C_LAYER_WEIGHT", "AOENV_C_DM_GX", "AOENV_C_DM_GY", "AOENV_C_DM_MODES",
              "AOENV_C_ACT_IDX", "AOENV_C_WFS_AMP", "AOENV_C_SH_SUBAP_IDX", "AOENV_C_SH_REF", "AOENV_C_WFS_UNITS",
-             "AOENV_C_RECON", "AOENV_B_SCREEN", "AOENV_B_OPD_ATM", "AOENV_B_COEFS", "AOENV_B_PHASE", "AOENV_B_FRAME",
+             "AOENV_C_RECON", "AOENV_C_PYR_MASK", "AOENV_C_PYR_TT", "AOENV_C_RECON_FACTORS", "AOENV_WFS_PYRAMID", "AOENV_B_SCREEN", "AOENV_B_OPD_ATM", "AOENV_B_COEFS", "AOENV_B_PHASE", "AOENV_B_FRAME",
              "AOENV_B_SIGNAL", "AOENV_B_TOTAL", "AOENV_B_RESIDUAL", "AOENV_B_WFS_MAX", "AOENV_B_XI", "AOENV_K_COUNT",
-             "AOENV_OPT_FAST_WFS", "AOENV_OPT_MFMA_GEMM", "AOENV_OPT_FAST_TRIG", "AOENV_OPT_STORE_ATM_OPD"]
+             "AOENV_OPT_FAST_WFS", "AOENV_OPT_MFMA_GEMM", "AOENV_OPT_FAST_TRIG", "AOENV_OPT_STORE_ATM_OPD", "AOENV_OPT_FUSED_TAIL"]
     prog += [f'printf("{e} %d\\n", (int){e});' for e in enums]
     prog += ["return 0;}"]
     src = tmp_path / "layout.c"
@@ -65,12 +65,13 @@ def test_cfg_layout_and_enums_match_header(built_lib, tmp_path):
                   AOENV_C_INNER_IDX=L.C_INNER_IDX, AOENV_C_OUTER_IDX=L.C_OUTER_IDX, AOENV_C_LAYER_WEIGHT=L.C_LAYER_WEIGHT,
                   AOENV_C_DM_GX=L.C_DM_GX, AOENV_C_DM_GY=L.C_DM_GY, AOENV_C_DM_MODES=L.C_DM_MODES, AOENV_C_ACT_IDX=L.C_ACT_IDX,
                   AOENV_C_WFS_AMP=L.C_WFS_AMP, AOENV_C_SH_SUBAP_IDX=L.C_SH_SUBAP_IDX, AOENV_C_SH_REF=L.C_SH_REF,
-                  AOENV_C_WFS_UNITS=L.C_WFS_UNITS, AOENV_C_RECON=L.C_RECON, AOENV_B_SCREEN=L.B_SCREEN,
+                  AOENV_C_WFS_UNITS=L.C_WFS_UNITS, AOENV_C_RECON=L.C_RECON, AOENV_C_PYR_MASK=L.C_PYR_MASK, AOENV_C_PYR_TT=L.C_PYR_TT,
+                  AOENV_C_RECON_FACTORS=L.C_RECON_FACTORS, AOENV_WFS_PYRAMID=L.WFS_PYRAMID, AOENV_B_SCREEN=L.B_SCREEN,
                   AOENV_B_OPD_ATM=L.B_OPD_ATM, AOENV_B_COEFS=L.B_COEFS, AOENV_B_PHASE=L.B_PHASE, AOENV_B_FRAME=L.B_FRAME,
                   AOENV_B_SIGNAL=L.B_SIGNAL, AOENV_B_TOTAL=L.B_TOTAL, AOENV_B_RESIDUAL=L.B_RESIDUAL,
                   AOENV_B_WFS_MAX=L.B_WFS_MAX, AOENV_B_XI=L.B_XI, AOENV_K_COUNT=len(L.KERNEL_NAMES),
                   AOENV_OPT_FAST_WFS=L.OPT_FAST_WFS, AOENV_OPT_MFMA_GEMM=L.OPT_MFMA_GEMM, AOENV_OPT_FAST_TRIG=L.OPT_FAST_TRIG,
-                  AOENV_OPT_STORE_ATM_OPD=L.OPT_STORE_ATM_OPD)
+                  AOENV_OPT_STORE_ATM_OPD=L.OPT_STORE_ATM_OPD, AOENV_OPT_FUSED_TAIL=L.OPT_FUSED_TAIL)
     for k, v in mirror.items():
         assert int(out[k]) == v, k
 
