@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define AOENV_ABI_VERSION 2
+#define AOENV_ABI_VERSION 3
 
 enum { AOENV_F32 = 0, AOENV_F64 = 1 };
 enum { AOENV_WFS_SH = 0, AOENV_WFS_PYRAMID = 1 };
@@ -140,6 +140,14 @@ int aoenv_set_wind(AoEnv* env, const double* h_ratio, int reset_buff);
  * seeds every MT19937 stream, draws the first ring X = A.Z + B.xi on the device, rebuilds mapShift,
  * clears the sub-pixel accumulators and refreshes atm.OPD (fill_phase_support + set_OPD). */
 int aoenv_new_screens(AoEnv* env, const double* h_screens, const uint32_t* h_ring_seeds, void* stream);
+
+/* Same, with the screens themselves generated on the device (OOPAO/phaseStats.py:190-318 ft_sh_phase_screen:
+ * FFT screen + 3 sub-harmonic grids, both seeded with the same RandomState as the reference does):
+ *   h_screen_seeds [n_env][n_layer] uint32: seed + layer of each layer's own RandomState (OOPAO/Atmosphere.py:574);
+ *   r0 [m @ 500 nm], L0 [m], pixel_size = layer.D / layer.resolution [m] (= telescope pixel size for fov 0).
+ * MT19937 + legacy Gaussian stream, float64 FFT: agrees with the NumPy generator to ~1e-12 rad. */
+int aoenv_new_screens_device(AoEnv* env, const uint32_t* h_screen_seeds, const uint32_t* h_ring_seeds, double r0,
+                             double L0, double pixel_size, void* stream);
 
 /* Replaces: atm.update(OPD) with a user-defined OPD (OOPAO/Atmosphere.py:421-425) and
  * tel.OPD = ... in the WFS calibration (OOPAO/ShackHartmann.py:296-297).  h_opd [n_env][R*R] float64

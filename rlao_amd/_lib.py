@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AOENV_LIB") or os.path.join(_HERE, "csrc", "libaoenv.so")   # AOENV_LIB: A/B kernel builds
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 F32, F64 = 0, 1
 WFS_SH, WFS_PYRAMID = 0, 1
 
@@ -41,6 +41,8 @@ EXPORTS = {
     "aoenv_upload": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
     "aoenv_set_wind": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "aoenv_new_screens": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "aoenv_new_screens_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double,
+                                           C.c_void_p]),
     "aoenv_set_atm_opd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "aoenv_set_coefs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "aoenv_measure": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -179,4 +179,20 @@ struct PyrSlopeArgs {
 template <typename T>
 int launch_pyramid(const PyrArgs<T>& base, const PyrSlopeArgs<T>& sl, int n_theta, int chunk, hipStream_t st);
 
+// ---- episode reset: von Karman screens on the device (screen_kernels.hip) ---------------------------------
+struct ScreenArgs {
+    const double* nrm;       // [E][2 N^2] normals of this layer: real parts then imaginary parts
+    const double* amp;       // [N^2]      sqrt(PSD_phi) * del_f on the frequency grid (PSD[N/2][N/2] = 0)
+    const double* sub;       // [12][3]    sub-harmonic terms (amplitude, fx, fy), order p = 1..3, (i, j) in {0,1}^2
+    const double* tw;        // [N][2]
+    cx<double>* scratch;     // [E][N][N]
+    double* hi;              // [E][N][N]  high-frequency screen
+    FftPlan plan;
+    int N, n_env, seq_per_block;
+    double delta;            // layer pixel size [m]
+};
+// writes layer.phase (rad @ 500 nm) of n_env envs into the interior of their (N+2)^2 mapShift
+template <typename T>
+int launch_screen(const ScreenArgs& base, T* map, int S, hipStream_t st);
+
 }  // namespace ao

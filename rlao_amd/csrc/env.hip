@@ -1,4 +1,5 @@
 // Host side of libaoenv: the AoEnv object, the atmosphere clock and the C ABI of include/aoenv.h.
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -758,6 +759,25 @@ static int require_step_constants(AoEnv* env, bool atmosphere) {
     return 0;
 }
 
+// ring RandomState seeding, first ring X = A.Z + B.xi, accumulators, atm.OPD: the part of generateNewPhaseScreen
+// after the new interior is in mapShift (OOPAO/Atmosphere.py:579-592)
+static int finish_new_screens(AoEnv* env, const uint32_t* h_ring_seeds, hipStream_t st) {
+    const int E = env->E, L = env->L;
+    std::vector<uint32_t> keys((size_t)L * E * kMtN);
+    std::vector<int> pos((size_t)L * E, kMtN);
+    for (int l = 0; l < L; ++l)
+        for (int e = 0; e < E; ++e) mt_seed(h_ring_seeds[(size_t)e * L + l], &keys[((size_t)l * E + e) * kMtN]);
+    AO_HIP(hipMemcpy(env->mt_state, keys.data(), keys.size() * 4, hipMemcpyHostToDevice));
+    AO_HIP(hipMemcpy(env->mt_pos, pos.data(), pos.size() * 4, hipMemcpyHostToDevice));
+    for (int l = 0; l < L; ++l) {
+        env->clk[l].buff[0] = env->clk[l].buff[1] = 0;            // notDoneOnce (OOPAO/Atmosphere.py:586, 359-364)
+        AO_TRY(AO_DISPATCH(env, extrude, env, l, 0, 0, false, st));
+    }
+    env->atm_user_defined = false;
+    AO_TRY(AO_DISPATCH(env, run_phase, env, 1, 1, st));            // fill_phase_support + set_OPD + atm*tel
+    return 0;
+}
+
 int aoenv_new_screens(AoEnv* env, const double* h_screens, const uint32_t* h_ring_seeds, void* stream) {
     AO_CHECK_ENV(env);
     if (env->L == 0) return fail("no atmosphere in this shard");
@@ -783,19 +803,105 @@ int aoenv_new_screens(AoEnv* env, const double* h_screens, const uint32_t* h_rin
             AO_HIP(hipMemcpy(env->screen_ptr(env->cur[l], l), host.data(), host.size(), hipMemcpyHostToDevice));
         }
     }
-    std::vector<uint32_t> keys((size_t)L * E * kMtN);
-    std::vector<int> pos((size_t)L * E, kMtN);
-    for (int l = 0; l < L; ++l)
-        for (int e = 0; e < E; ++e) mt_seed(h_ring_seeds[(size_t)e * L + l], &keys[((size_t)l * E + e) * kMtN]);
-    AO_HIP(hipMemcpy(env->mt_state, keys.data(), keys.size() * 4, hipMemcpyHostToDevice));
-    AO_HIP(hipMemcpy(env->mt_pos, pos.data(), pos.size() * 4, hipMemcpyHostToDevice));
-    for (int l = 0; l < L; ++l) {
-        env->clk[l].buff[0] = env->clk[l].buff[1] = 0;            // notDoneOnce (OOPAO/Atmosphere.py:586, 359-364)
-        AO_TRY(AO_DISPATCH(env, extrude, env, l, 0, 0, false, st));
+    return finish_new_screens(env, h_ring_seeds, st);
+}
+
+namespace {
+struct TmpFree {                                   // scratch of one reset: released on every exit path
+    std::vector<void*> p;
+    ~TmpFree() { for (void* q : p) (void)hipFree(q); }
+    int get(void** out, size_t bytes) {
+        AO_HIP(hipMalloc(out, bytes));
+        p.push_back(*out);
+        return 0;
     }
-    env->atm_user_defined = false;
-    AO_TRY(AO_DISPATCH(env, run_phase, env, 1, 1, st));            // fill_phase_support + set_OPD + atm*tel
-    return 0;
+};
+
+// von Karman spectrum of OOPAO/phaseStats.py:206-207 (l0 = 1e-10 m: the inner-scale roll-off is 1 in float64)
+double vk_psd(double f, double r0, double L0) {
+    const double fm = 5.92 / 1e-10 / (2 * 3.14159265358979323846), f0 = 1.0 / L0;
+    return 0.023 * std::pow(r0, -5.0 / 3) * std::exp(-((f / fm) * (f / fm))) / std::pow(f * f + f0 * f0, 11.0 / 6);
+}
+}  // namespace
+
+int aoenv_new_screens_device(AoEnv* env, const uint32_t* h_screen_seeds, const uint32_t* h_ring_seeds, double r0,
+                             double L0, double pixel_size, void* stream) {
+    AO_CHECK_ENV(env);
+    if (env->L == 0) return fail("no atmosphere in this shard");
+    AO_TRY(require_step_constants(env, true));
+    if (!h_screen_seeds || !h_ring_seeds) return fail("null seeds");
+    if (!(r0 > 0) || !(L0 > 0) || !(pixel_size > 0)) return fail("r0, L0 and the pixel size must be positive");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    AO_HIP(hipStreamSynchronize(st));
+    const int E = env->E, L = env->L, N = env->N, S = env->S;
+    if (N % 2) return fail("the screen generator needs an even layer size, got %d", N);
+    const size_t N2 = (size_t)N * N;
+
+    // frequency-grid amplitude sqrt(PSD) del_f (phaseStats.py:209-222) and the 3 x 4 sub-harmonic terms (:277-309)
+    std::vector<double> amp(N2), sub(36), tw(2 * (size_t)N);
+    const double del_f = 1.0 / (N * pixel_size);
+    for (int y = 0; y < N; ++y)
+        for (int x = 0; x < N; ++x) {
+            const double fx = (x - N / 2.0) * del_f, fy = (y - N / 2.0) * del_f;
+            amp[(size_t)y * N + x] = std::sqrt(vk_psd(std::sqrt(fx * fx + fy * fy), r0, L0)) * del_f;
+        }
+    amp[(size_t)(N / 2) * N + N / 2] = 0;
+    const double D = N * pixel_size;
+    for (int p = 1; p <= 3; ++p) {
+        const double df = 1.0 / (std::pow(3.0, p) * D);
+        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j) {
+                const double fx = (j - 1) * df, fy = (i - 1) * df;
+                double* t = &sub[3 * (4 * (p - 1) + 2 * i + j)];
+                t[0] = (i == 1 && j == 1) ? 0.0 : std::sqrt(vk_psd(std::sqrt(fx * fx + fy * fy), r0, L0)) * df;
+                t[1] = fx;
+                t[2] = fy;
+            }
+    }
+    const double pi = 3.14159265358979323846;
+    for (int k = 0; k < N; ++k) { tw[2 * k] = std::cos(2 * pi * k / N); tw[2 * k + 1] = -std::sin(2 * pi * k / N); }
+
+    ScreenArgs sa{};
+    AO_TRY(make_fft_plan(N, &sa.plan));
+    sa.N = N;
+    sa.delta = pixel_size;
+    const size_t per_env = 40 * N2;                                // normals + complex scratch + real screen, float64
+    int EC = (int)std::min<size_t>((size_t)E, std::max<size_t>(1, ((size_t)1 << 30) / per_env));
+    TmpFree tmp;
+    double *d_amp, *d_sub, *d_tw, *d_nrm, *d_hi;
+    void* d_scr;
+    uint32_t* d_mt;
+    int* d_pos;
+    AO_TRY(tmp.get((void**)&d_amp, N2 * 8));
+    AO_TRY(tmp.get((void**)&d_sub, 36 * 8));
+    AO_TRY(tmp.get((void**)&d_tw, 2 * (size_t)N * 8));
+    AO_TRY(tmp.get((void**)&d_nrm, (size_t)EC * 2 * N2 * 8));
+    AO_TRY(tmp.get(&d_scr, (size_t)EC * N2 * 16));
+    AO_TRY(tmp.get((void**)&d_hi, (size_t)EC * N2 * 8));
+    AO_TRY(tmp.get((void**)&d_mt, (size_t)EC * kMtN * 4));
+    AO_TRY(tmp.get((void**)&d_pos, (size_t)EC * 4));
+    AO_HIP(hipMemcpy(d_amp, amp.data(), N2 * 8, hipMemcpyHostToDevice));
+    AO_HIP(hipMemcpy(d_sub, sub.data(), 36 * 8, hipMemcpyHostToDevice));
+    AO_HIP(hipMemcpy(d_tw, tw.data(), tw.size() * 8, hipMemcpyHostToDevice));
+    sa.amp = d_amp; sa.sub = d_sub; sa.tw = d_tw; sa.nrm = d_nrm; sa.hi = d_hi;
+    sa.scratch = reinterpret_cast<cx<double>*>(d_scr);
+    std::vector<uint32_t> keys((size_t)EC * kMtN);
+    std::vector<int> pos((size_t)EC, kMtN);
+    for (int l = 0; l < L; ++l)
+        for (int e0 = 0; e0 < E; e0 += EC) {
+            const int ne = std::min(EC, E - e0);
+            // the layer's own RandomState(seed + layer) draws normal(size=(N, N)) twice (real, imaginary parts)
+            for (int e = 0; e < ne; ++e) mt_seed(h_screen_seeds[(size_t)(e0 + e) * L + l], &keys[(size_t)e * kMtN]);
+            AO_HIP(hipMemcpyAsync(d_mt, keys.data(), (size_t)ne * kMtN * 4, hipMemcpyHostToDevice, st));
+            AO_HIP(hipMemcpyAsync(d_pos, pos.data(), (size_t)ne * 4, hipMemcpyHostToDevice, st));
+            AO_TRY(launch_mt_normal<double>(d_mt, d_pos, d_nrm, ne, (int)(2 * N2), 0, (int)(2 * N2), st));
+            sa.n_env = ne;
+            char* map = static_cast<char*>(env->screen_ptr(env->cur[l], l)) + (size_t)e0 * S * S * env->esz;
+            if (env->esz == 4) AO_TRY(launch_screen<float>(sa, reinterpret_cast<float*>(map), S, st));
+            else AO_TRY(launch_screen<double>(sa, reinterpret_cast<double*>(map), S, st));
+            AO_HIP(hipStreamSynchronize(st));                      // keys / pos are reused by the next chunk
+        }
+    return finish_new_screens(env, h_ring_seeds, st);
 }
 
 int aoenv_set_atm_opd(AoEnv* env, const double* h_opd, void* stream) {

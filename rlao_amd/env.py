@@ -66,6 +66,12 @@ class Shard:
         L.check(self.lib.aoenv_new_screens(self.h, None if s is None else s.ctypes.data_as(C.c_void_p),
                                            k.ctypes.data_as(C.c_void_p), C.c_void_p(stream)))
 
+    def new_screens_device(self, screen_seeds, ring_seeds, r0, L0, pixel_size, stream=0):
+        a = np.ascontiguousarray(screen_seeds, dtype=np.uint32)
+        k = np.ascontiguousarray(ring_seeds, dtype=np.uint32)
+        L.check(self.lib.aoenv_new_screens_device(self.h, a.ctypes.data_as(C.c_void_p), k.ctypes.data_as(C.c_void_p),
+                                                  float(r0), float(L0), float(pixel_size), C.c_void_p(stream)))
+
     def set_atm_opd(self, opd, stream=0):
         a = None if opd is None else np.ascontiguousarray(opd, dtype=np.float64)
         L.check(self.lib.aoenv_set_atm_opd(self.h, None if a is None else a.ctypes.data_as(C.c_void_p), C.c_void_p(stream)))
@@ -548,17 +554,25 @@ class BatchedAOEnv:
         idx = np.arange(self.n_envs, dtype=np.int64) + self.env_index_offset
         return int(seed) + idx * self.env_seed_stride
 
-    def generate_new_phase_screen(self, seed=None):
+    def generate_new_phase_screen(self, seed=None, on_host=False):
         """atm.generateNewPhaseScreen(seed) for every env; env e uses ``seed + e * env_seed_stride``
-        (layer l: screen seed + l, ring RandomState seed + 1000 l -- OOPAO/Atmosphere.py:574-579)."""
+        (layer l: screen seed + l, ring RandomState seed + 1000 l -- OOPAO/Atmosphere.py:574-579).
+        The screens are drawn on the device (same MT19937 stream and spectrum as the reference, float64 FFT);
+        ``on_host=True`` draws them with NumPy instead and uploads them (cross-check of the device generator)."""
         import time as _t
         if seed is None:
             t = _t.localtime()
             seed = t.tm_hour * 3600 + t.tm_min * 60 + t.tm_sec
         p, at = self.param, self._atm_tables
         seeds = self.env_seeds(seed)
-        jobs = [(int(s), l) for s in seeds for l in range(p.nLayer)]
         delta = at.layer_D / at.N
+        ring = np.array([[(int(s) + 1000 * l) & 0xFFFFFFFF for l in range(p.nLayer)] for s in seeds], dtype=np.uint32)
+        if not on_host:
+            scr = np.array([[(int(s) + l) & 0xFFFFFFFF for l in range(p.nLayer)] for s in seeds], dtype=np.uint32)
+            self._shard.new_screens_device(scr, ring, p.r0, p.L0, delta, self._stream())
+            self._push_wind(reset=True)
+            return
+        jobs = [(int(s), l) for s in seeds for l in range(p.nLayer)]
 
         def make(job):
             return calib.new_phase_screen(p.r0, p.L0, at.N, delta, job[0] + job[1])
@@ -569,7 +583,6 @@ class BatchedAOEnv:
         else:
             screens = [make(j) for j in jobs]
         screens = np.stack(screens).reshape(self.n_envs, p.nLayer, at.N * at.N)
-        ring = np.array([[(int(s) + 1000 * l) & 0xFFFFFFFF for l in range(p.nLayer)] for s in seeds], dtype=np.uint32)
         self._shard.new_screens(screens, ring, self._stream())
         self._push_wind(reset=True)
 

@@ -193,3 +193,37 @@ def test_c_abi_reports_errors():
     # the env still works after the rejected calls
     env.step(0, np.zeros((2, 9, 9), dtype=np.float32))
     env.close()
+
+
+@pytest.mark.parametrize("dtype,n_layer", [("f64", 1), ("f32", 3)])
+def test_device_phase_screens_match_oracle(dtype, n_layer):
+    """aoenv_new_screens_device (MT19937 normals, float64 FFT + sub-harmonics on the GPU) against the oracle's
+    restatement of ft_sh_phase_screen (OOPAO/phaseStats.py:243-318), for every env and layer of the shard; and the
+    NumPy upload path gives the same loop."""
+    from oracle import ao_oracle as O                       # checker only
+    from rlao_amd import _lib as L
+    from rlao_amd.env import BatchedAOEnv
+    geo = dict(SMALL, windSpeed=[10.0, 7.0, 12.0][:n_layer], windDirection=[72.0, 0.0, 144.0][:n_layer],
+               fractionalR0=[[1.0], None, [0.6, 0.25, 0.15]][n_layer - 1], altitude=[0.0] * n_layer)
+    env = BatchedAOEnv(n_envs=5, device=0, dtype=dtype)
+    env.set_params(geo, wfs_type="shackhartmann")
+    env.env_seed_stride = 7
+    env.generate_new_phase_screen(41)
+    at = env._atm_tables
+    S, N = at.S, at.N
+    maps = env._shard.download(L.B_SCREEN, (n_layer, 5, S, S))
+    tol = 1e-9 if dtype == "f64" else 2e-5
+    for e, seed in enumerate(env.env_seeds(41)):
+        for l in range(n_layer):
+            want = O.ft_sh_phase_screen(geo["r0"], geo["L0"], N, at.layer_D / N, int(seed) + l)
+            np.testing.assert_allclose(maps[l, e, 1:-1, 1:-1], want, rtol=0, atol=tol)
+    env.dm.coefs = 0
+    env.measure()
+    obs_dev = env.reset_soft().cpu().numpy()
+    env.generate_new_phase_screen(41, on_host=True)
+    maps_host = env._shard.download(L.B_SCREEN, (n_layer, 5, S, S))
+    np.testing.assert_allclose(maps, maps_host, rtol=0, atol=tol * 10)       # the ring X = A Z + B xi amplifies 1e-12
+    env.dm.coefs = 0
+    env.measure()
+    np.testing.assert_allclose(env.reset_soft().cpu().numpy(), obs_dev, atol=1e-6 if dtype == "f64" else 3e-5)
+    env.close()
