@@ -182,6 +182,11 @@ int aoenv_step(AoEnv* env, int i, const void* d_action, void* d_obs, void* d_fra
 int aoenv_run_integrator(AoEnv* env, int i0, int n_steps, double gain, void* d_obs, void* d_frame,
                          void* d_reward, void* d_strehl, void* stream);
 
+/* Episode return on the device (the sum of rewards the trainers accumulate on the host, MAIN/PO4AO/mbrl.py:64-89):
+ * d_return [n_env] is a caller-owned device buffer of the env dtype; every aoenv_step / integrator step adds its reward
+ * to it.  NULL detaches it.  The caller zeroes it at the start of an episode. */
+int aoenv_set_return_accumulator(AoEnv* env, void* d_return);
+
 /* State access (get_state / set_state; also the stage boundaries compared by the
  * parity tests).  `which` is an AoBuf.  aoenv_buffer returns the device pointer and size in bytes;
  * aoenv_download copies to a host buffer of the env dtype and synchronises the stream. */
@@ -200,6 +205,9 @@ enum AoOption {
                                 re-derived from the screens when it is downloaded */
     AOENV_OPT_FUSED_TAIL = 4, /* 1 (default): when AOENV_C_RECON_FACTORS is uploaded, SH centroid + low-rank R.s + epilogue run as
                                  one per-env kernel; 0: separate centroid / MFMA GEMM / epilogue kernels */
+    AOENV_OPT_FUSED_STEP = 5, /* 1 (default): float32 SH shards with 6 px per lenslet, <= 336 valid lenslets, R <= 128 and uploaded
+                                 AOENV_C_RECON_FACTORS run the whole step as ONE kernel, one workgroup per env, every intermediate in LDS;
+                                 0: the separate phase / spots / tail kernels */
     AOENV_OPT_FAST_TRIG = 2  /* 1 (default): v_sin/v_cos after Cody-Waite reduction in the float32 SH kernel; 0: sincosf */
 };
 int aoenv_set_option(AoEnv* env, int option, int value);
@@ -210,7 +218,7 @@ int aoenv_set_option(AoEnv* env, int option, int value);
  * AoKernel.  aoenv_profile(env, 0|1) also clears the recorded events. */
 enum AoKernel {
     AOENV_K_SHIFT_GATHER = 0, AOENV_K_MT_NORMAL, AOENV_K_GEMM_RING, AOENV_K_SCATTER, AOENV_K_PHASE,
-    AOENV_K_SH_SPOTS, AOENV_K_SH_CENTROID, AOENV_K_GEMM_RECON, AOENV_K_RECON_FINISH, AOENV_K_PYRAMID, AOENV_K_SH_TAIL, AOENV_K_COUNT
+    AOENV_K_SH_SPOTS, AOENV_K_SH_CENTROID, AOENV_K_GEMM_RECON, AOENV_K_RECON_FINISH, AOENV_K_PYRAMID, AOENV_K_SH_TAIL, AOENV_K_ENV_STEP, AOENV_K_COUNT
 };
 int aoenv_profile(AoEnv* env, int enable);
 int aoenv_profile_read(AoEnv* env, double* h_ms, int32_t* h_count, void* stream);

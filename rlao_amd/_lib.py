@@ -19,9 +19,9 @@ WFS_SH, WFS_PYRAMID = 0, 1
 (B_SCREEN, B_OPD_ATM, B_COEFS, B_PHASE, B_FRAME, B_SIGNAL, B_TOTAL, B_RESIDUAL, B_WFS_MAX, B_XI) = range(10)
 
 
-OPT_FAST_WFS, OPT_MFMA_GEMM, OPT_FAST_TRIG, OPT_STORE_ATM_OPD, OPT_FUSED_TAIL = 0, 1, 2, 3, 4
+OPT_FAST_WFS, OPT_MFMA_GEMM, OPT_FAST_TRIG, OPT_STORE_ATM_OPD, OPT_FUSED_TAIL, OPT_FUSED_STEP = 0, 1, 2, 3, 4, 5
 KERNEL_NAMES = ("shift_gather", "mt_normal", "gemm_ring", "scatter_minmax", "phase", "sh_spots", "sh_centroid",
-                "gemm_recon", "recon_finish", "pyramid", "sh_tail")
+                "gemm_recon", "recon_finish", "pyramid", "sh_tail", "env_step")
 
 
 class AoCfg(C.Structure):
@@ -51,6 +51,7 @@ EXPORTS = {
                              C.c_void_p]),
     "aoenv_run_integrator": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p]),
+    "aoenv_set_return_accumulator": (C.c_int, [C.c_void_p, C.c_void_p]),
     "aoenv_buffer": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "aoenv_download": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "aoenv_upload_state": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),

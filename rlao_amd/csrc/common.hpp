@@ -93,6 +93,17 @@ struct PhaseBuffers {
 };
 int phase_tiles(int R);
 template <typename T>
+struct KArgs {                 // kernel argument block of the phase kernels
+    PhaseArgs pa;
+    PhaseBuffers<T> pb;
+    int R, n_act, n_valid_act, tx, rp, ablate;
+    T atm_scale;   // lambda_atm / 2 pi
+    T src_scale;   // 2 pi / lambda_src
+};
+template <typename T>
+KArgs<T> make_phase_kargs(const PhaseArgs& pa, const PhaseBuffers<T>& pb, int R, int n_act, int n_valid_act,
+                          double atm_wavelength, double src_wavelength);
+template <typename T>
 int launch_phase(const PhaseArgs& pa, const PhaseBuffers<T>& pb, int n_env, int R, int n_act, int n_valid_act,
                  double atm_wavelength, double src_wavelength, int use_mfma, hipStream_t st);
 
@@ -125,6 +136,7 @@ struct FinishArgs {
     T* coefs;                // [E][A]
     T* obs;                  // [E][nAct^2]
     T* reward;               // [E] or null
+    T* ret;                  // [E] or null: episode return accumulator, += reward every step
     T* strehl;               // [E] or null
     T* scal;                 // [E][4] total_nm, residual_nm, strehl
     T* total;                // [n_loop][E]
@@ -142,6 +154,25 @@ template <typename T>
 int launch_sh_tail(const T* frame, const T* wfs_max, const ShConst<T>& sc, T* signal, const T* fac_m,
                    const T* fac_m2c_t, int n_modes, const FinishArgs<T>& fa, int n_env, int R, int n_subap, int n_valid,
                    int max_group, hipStream_t st);
+// fused per-env step kernel (step_kernel.hip): float32, 6 px per lenslet, separable DM, factored reconstructor
+struct StepArgs {
+    KArgs<float> k;
+    ShConst<float> sc;
+    FinishArgs<float> fa;        // n_tiles must be 1: the kernel leaves its telemetry sums in part[e][0][:]
+    float* frame;                // [E][R*R]
+    float* signal;               // [E][2 nValid]
+    float* wfs_max;              // [E]
+    const float* fac_m;          // [K][nSig]
+    const float* fac_m2c_t;      // [K][A]
+    const short* slot_of;        // [nSub^2] lenslet -> index among the valid ones, -1 = not valid
+    const float* amp_pupil;      // [R*R] WFS field amplitude inside the pupil, -1 outside (pupil and amp in one load)
+    const float* gxa;            // [128][4][8] gx[x][q + 4 s] at [x][q][s], zero padded: MFMA operands as two 16-byte loads
+    const float* gya;            // [128][4][8] gy[y][q + 4 s]
+    int n_modes, n_subap, n_valid, n_env;
+};
+int step_fused_supported(int R, int n_subap, int n_valid, int n_act, int n_modes);
+int launch_env_step(const StepArgs& a, hipStream_t st);
+
 template <typename T>
 int launch_convert_from_f64(const double* src, T* dst, size_t n, hipStream_t st);
 

@@ -71,6 +71,13 @@ struct AoEnv {
     void* amp = nullptr;
     int* subap_idx = nullptr;
     uint8_t* valid2d = nullptr;             // [nSub*nSub]
+    short* slot_of = nullptr;               // [nSub*nSub] lenslet -> compact valid index, -1 = not valid
+    float* amp_pupil = nullptr;             // [R*R] fused step kernel: amplitude inside the pupil, -1 outside
+    float* gxa = nullptr;                   // [128][4][8] fused step kernel: gx / gy re-laid out as MFMA operand pairs
+    float* gya = nullptr;
+    std::vector<uint8_t> h_pupil;           // host copies, to rebuild amp_pupil
+    std::vector<double> h_amp;
+    bool amp_pupil_dirty = true;
     void* sh_ref = nullptr;
     void* tw = nullptr;
     void* phs = nullptr;
@@ -90,12 +97,14 @@ struct AoEnv {
     int pyr_chunk = 1;
     void* vbuf = nullptr;                   // [E][A]
     void* obs_scratch = nullptr;            // [E][nAct*nAct]
+    void* ret_acc = nullptr;                // caller-owned [E] episode-return accumulator (aoenv_set_return_accumulator)
     std::vector<void*> allocs;
     // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
     bool use_fast_wfs = true;               // aoenv_set_option(AOENV_OPT_FAST_WFS)
     bool use_mfma = true;                   // aoenv_set_option(AOENV_OPT_MFMA_GEMM)
     bool use_fast_trig = true;              // aoenv_set_option(AOENV_OPT_FAST_TRIG)
     bool use_fused_tail = true;             // aoenv_set_option(AOENV_OPT_FUSED_TAIL); needs AOENV_C_RECON_FACTORS
+    bool use_fused_step = true;             // aoenv_set_option(AOENV_OPT_FUSED_STEP): the whole step in one kernel
     bool store_opd_atm = false;             // aoenv_set_option(AOENV_OPT_STORE_ATM_OPD): write atm.OPD every step
     bool atm_user_defined = false;          // aoenv_set_atm_opd() until the next step / new screens
     int debug_ablate = 0;                   // aoenv_set_option(99): skip kernel sections (timing diagnosis only)
@@ -254,38 +263,13 @@ int advance_atmosphere(AoEnv* env, hipStream_t st) {
 }
 
 template <typename T>
+void fill_phase_args(AoEnv* env, PhaseArgs& pa, PhaseBuffers<T>& pb, int update_atm, int store_atm, int store_phase);
+
+template <typename T>
 int run_phase(AoEnv* env, int update_atm, int store_atm, hipStream_t st, int store_phase = 1) {
-    PhaseArgs pa{};
-    pa.n_layer = env->L;
-    pa.S = env->S;
-    pa.foot = (env->N / 2 - env->R / 2) + 1;
-    pa.update_atm = (update_atm && env->L > 0 && !env->atm_user_defined) ? 1 : 0;
-    pa.store_atm = store_atm;
-    pa.store_phase = store_phase;
-    for (int l = 0; l < env->L; ++l) {
-        pa.screen[l] = env->screen_ptr(env->cur[l], l);
-        pa.minmax[l] = env->minmax_ptr(l);
-        LayerTaps& t = pa.taps[l];
-        const double fy = -env->clk[l].buff[1], fx = -env->clk[l].buff[0];
-        const double ky = std::floor(fy), kx = std::floor(fx);
-        t.dy = (int)ky;
-        t.dx = (int)kx;
-        catmull_rom(fy - ky, t.wy);
-        catmull_rom(fx - kx, t.wx);
-        t.weight = env->layer_weight[l];
-    }
-    PhaseBuffers<T> pb{};
-    pb.opd_atm = env->as<T>(env->opd_atm);
-    pb.coefs = env->as<T>(env->coefs);
-    pb.dm_opd = env->c.dm_separable ? nullptr : env->as<T>(env->dm_opd);
-    pb.gx = env->as<T>(env->gx);
-    pb.gy = env->as<T>(env->gy);
-    pb.gxt = env->as<T>(env->gxt);
-    pb.act_idx = env->act_idx;
-    pb.pupil = env->pupil;
-    pb.phase = env->as<T>(env->phase);
-    pb.part = env->part;
-    pb.wfs_max = env->as<T>(env->wfs_max);
+    PhaseArgs pa;
+    PhaseBuffers<T> pb;
+    fill_phase_args<T>(env, pa, pb, update_atm, store_atm, store_phase);
     AO_PROF(env, PHASE, st);
     return launch_phase<T>(pa, pb, env->E, env->R, env->nAct, env->A, env->c.atm_wavelength, env->c.src_wavelength,
                            (env->use_mfma ? 1 : 0) | (env->debug_ablate << 8), st);
@@ -359,6 +343,7 @@ FinishArgs<T> finish_args(AoEnv* env, const T* d_action, T* d_obs, T* d_reward, 
     fa.coefs = env->as<T>(env->coefs);
     fa.obs = d_obs;
     fa.reward = d_reward;
+    fa.ret = env->as<T>(env->ret_acc);
     fa.strehl = d_strehl;
     fa.scal = env->as<T>(env->scal);
     fa.total = env->as<T>(env->total);
@@ -394,11 +379,103 @@ int run_recon(AoEnv* env, const T* d_action, T* d_obs, T* d_reward, T* d_strehl,
     return 0;
 }
 
+// ---- the whole step as one kernel (step_kernel.hip) -------------------------------------------------------------
+template <typename T>
+bool fused_step_ok(const AoEnv*) { return false; }
+template <>
+bool fused_step_ok<float>(const AoEnv* env) {
+    return env->use_fused_step && env->use_fast_wfs && env->use_mfma && env->use_fused_tail && env->c.wfs_type == AOENV_WFS_SH && env->c.dm_separable && env->n_modes > 0 &&
+           env->c.max_group == 1 && env->L > 0 && env->c.cam_res == env->R && env->debug_ablate == 0 &&
+           step_fused_supported(env->R, env->nSub, env->nVal, env->nAct, env->n_modes) != 0;
+}
+
+template <typename T>
+void fill_phase_args(AoEnv* env, PhaseArgs& pa, PhaseBuffers<T>& pb, int update_atm, int store_atm, int store_phase) {
+    pa = PhaseArgs{};
+    pa.n_layer = env->L;
+    pa.S = env->S;
+    pa.foot = (env->N / 2 - env->R / 2) + 1;
+    pa.update_atm = (update_atm && env->L > 0 && !env->atm_user_defined) ? 1 : 0;
+    pa.store_atm = store_atm;
+    pa.store_phase = store_phase;
+    for (int l = 0; l < env->L; ++l) {
+        pa.screen[l] = env->screen_ptr(env->cur[l], l);
+        pa.minmax[l] = env->minmax_ptr(l);
+        LayerTaps& t = pa.taps[l];
+        const double fy = -env->clk[l].buff[1], fx = -env->clk[l].buff[0];
+        const double ky = std::floor(fy), kx = std::floor(fx);
+        t.dy = (int)ky;
+        t.dx = (int)kx;
+        catmull_rom(fy - ky, t.wy);
+        catmull_rom(fx - kx, t.wx);
+        t.weight = env->layer_weight[l];
+    }
+    pb = PhaseBuffers<T>{};
+    pb.opd_atm = env->as<T>(env->opd_atm);
+    pb.coefs = env->as<T>(env->coefs);
+    pb.dm_opd = env->c.dm_separable ? nullptr : env->as<T>(env->dm_opd);
+    pb.gx = env->as<T>(env->gx);
+    pb.gy = env->as<T>(env->gy);
+    pb.gxt = env->as<T>(env->gxt);
+    pb.act_idx = env->act_idx;
+    pb.pupil = env->pupil;
+    pb.phase = env->as<T>(env->phase);
+    pb.part = env->part;
+    pb.wfs_max = env->as<T>(env->wfs_max);
+}
+
+template <typename T>
+int run_fused_step(AoEnv*, int, const void*, void*, void*, void*, double, hipStream_t) { return fail("fused step: float32 only"); }
+template <>
+int run_fused_step<float>(AoEnv* env, int i, const void* d_action, void* d_obs, void* d_reward, void* d_strehl, double gain,
+                          hipStream_t st) {
+    if (env->amp_pupil_dirty) {
+        const size_t R2 = (size_t)env->R * env->R;
+        if (env->h_pupil.size() != R2 || env->h_amp.size() != R2) return fail("pupil / WFS amplitude have not been uploaded");
+        std::vector<float> t(R2);
+        for (size_t q = 0; q < R2; ++q) t[q] = env->h_pupil[q] ? (float)env->h_amp[q] : -1.f;
+        AO_HIP(hipMemcpyAsync(env->amp_pupil, t.data(), R2 * sizeof(float), hipMemcpyHostToDevice, st));
+        AO_HIP(hipStreamSynchronize(st));
+        env->amp_pupil_dirty = false;
+    }
+    StepArgs a{};
+    PhaseArgs pa;
+    PhaseBuffers<float> pb;
+    fill_phase_args<float>(env, pa, pb, 1, env->store_opd_atm ? 1 : 0, 1);
+    a.k = make_phase_kargs<float>(pa, pb, env->R, env->nAct, env->A, env->c.atm_wavelength, env->c.src_wavelength);
+    a.sc = sh_const<float>(env);
+    a.fa = finish_args<float>(env, static_cast<const float*>(d_action), static_cast<float*>(d_obs),
+                              static_cast<float*>(d_reward), static_cast<float*>(d_strehl), i, 1, gain, 1);
+    a.fa.n_tiles = 1;
+    a.frame = env->as<float>(env->frame);
+    a.signal = env->as<float>(env->signal);
+    a.wfs_max = env->as<float>(env->wfs_max);
+    a.fac_m = env->as<float>(env->fac_m);
+    a.fac_m2c_t = env->as<float>(env->fac_m2c_t);
+    a.slot_of = env->slot_of;
+    a.amp_pupil = env->amp_pupil;
+    a.gxa = env->gxa;
+    a.gya = env->gya;
+    a.n_modes = env->n_modes;
+    a.n_subap = env->nSub;
+    a.n_valid = env->nVal;
+    a.n_env = env->E;
+    AO_PROF(env, ENV_STEP, st);
+    return launch_env_step(a, st);
+}
+
 template <typename T>
 int step_t(AoEnv* env, int i, const void* d_action, void* d_obs, void* d_frame, void* d_reward, void* d_strehl,
            double gain, hipStream_t st) {
     AO_TRY(advance_atmosphere<T>(env, st));
     env->atm_user_defined = false;
+    if (fused_step_ok<T>(env)) {
+        AO_TRY(run_fused_step<T>(env, i, d_action, d_obs, d_reward, d_strehl, gain, st));
+        if (d_frame)
+            AO_HIP(hipMemcpyAsync(d_frame, env->frame, (size_t)env->E * env->c.cam_res * env->c.cam_res * sizeof(T),
+                                  hipMemcpyDeviceToDevice, st));
+        return 0;
+    }
     AO_TRY(run_phase<T>(env, 1, env->store_opd_atm ? 1 : 0, st));
     // one workgroup per env re-reads the factors from L2: wins while launch latency dominates (measured: 19.5 us vs
     // 32.5 us at 256 envs, 96 us vs 75 us at 2048), the batched MFMA GEMM path takes over for large shards
@@ -549,6 +626,10 @@ int aoenv_create(const AoCfg* cfg, int device, AoEnv** out) {
     A_(&e->amp, R2 * z);
     A_((void**)&e->subap_idx, (size_t)e->nVal * 4);
     A_((void**)&e->valid2d, (size_t)e->nSub * e->nSub);
+    A_((void**)&e->slot_of, (size_t)e->nSub * e->nSub * sizeof(short));
+    A_((void**)&e->amp_pupil, R2 * sizeof(float));
+    A_((void**)&e->gxa, (size_t)128 * 32 * sizeof(float));
+    A_((void**)&e->gya, (size_t)128 * 32 * sizeof(float));
     A_(&e->sh_ref, (size_t)2 * e->nVal * z);
     A_(&e->tw, (size_t)e->n * 2 * z);
     A_(&e->phs, (size_t)e->p * 2 * z);
@@ -618,6 +699,8 @@ int aoenv_upload(AoEnv* env, int kind, const void* h, size_t bytes) {
             AO_TRY(need(R2));
             AO_HIP(hipMemcpy(env->pupil, h, R2, hipMemcpyHostToDevice));
             const uint8_t* pu = static_cast<const uint8_t*>(h);
+            env->h_pupil.assign(pu, pu + R2);
+            env->amp_pupil_dirty = true;
             env->n_pupil = 0;
             for (size_t i = 0; i < R2; ++i) env->n_pupil += pu[i] != 0;
             break;
@@ -651,6 +734,12 @@ int aoenv_upload(AoEnv* env, int kind, const void* h, size_t bytes) {
         case AOENV_C_DM_GY:
             AO_TRY(need((size_t)env->R * env->nAct * 8));
             AO_TRY(upload_real(env, kind == AOENV_C_DM_GX ? env->gx : env->gy, d, (size_t)env->R * env->nAct));
+            if (env->R <= 128 && env->nAct <= 32) {                  // operand layout of the fused step kernel
+                std::vector<float> t((size_t)128 * 32, 0.f);
+                for (int x = 0; x < env->R; ++x)
+                    for (int k = 0; k < env->nAct; ++k) t[((size_t)x * 4 + (k & 3)) * 8 + (k >> 2)] = (float)d[(size_t)x * env->nAct + k];
+                AO_HIP(hipMemcpy(kind == AOENV_C_DM_GX ? env->gxa : env->gya, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
+            }
             if (kind == AOENV_C_DM_GX) {
                 const int nap = (env->nAct + 3) & ~3, rp = cdiv(env->R, 128) * 128;
                 std::vector<double> t((size_t)nap * rp, 0.0);
@@ -675,6 +764,8 @@ int aoenv_upload(AoEnv* env, int kind, const void* h, size_t bytes) {
         case AOENV_C_WFS_AMP:
             AO_TRY(need(R2 * 8));
             AO_TRY(upload_real(env, env->amp, d, R2));
+            env->h_amp.assign(d, d + R2);
+            env->amp_pupil_dirty = true;
             break;
         case AOENV_C_SH_SUBAP_IDX: {
             AO_TRY(need((size_t)env->nVal * 4));
@@ -685,6 +776,10 @@ int aoenv_upload(AoEnv* env, int kind, const void* h, size_t bytes) {
             std::vector<uint8_t> v2((size_t)env->nSub * env->nSub, 0);
             for (int i = 0; i < env->nVal; ++i) v2[ix[i]] = 1;
             AO_HIP(hipMemcpy(env->valid2d, v2.data(), v2.size(), hipMemcpyHostToDevice));
+            std::vector<short> so((size_t)env->nSub * env->nSub, (short)-1);
+            if (env->nVal <= 32767)
+                for (int i = 0; i < env->nVal; ++i) so[ix[i]] = (short)i;
+            AO_HIP(hipMemcpy(env->slot_of, so.data(), so.size() * sizeof(short), hipMemcpyHostToDevice));
             break;
         }
         case AOENV_C_SH_REF:
@@ -968,6 +1063,12 @@ int aoenv_run_integrator(AoEnv* env, int i0, int n_steps, double gain, void* d_o
     return 0;
 }
 
+int aoenv_set_return_accumulator(AoEnv* env, void* d_return) {
+    AO_CHECK_ENV(env);
+    env->ret_acc = d_return;
+    return 0;
+}
+
 int aoenv_buffer(AoEnv* env, int which, void** d_ptr, size_t* bytes) {
     AO_CHECK_ENV(env);
     BufInfo b{};
@@ -1037,6 +1138,7 @@ int aoenv_set_option(AoEnv* env, int option, int value) {
         case AOENV_OPT_FAST_TRIG: env->use_fast_trig = value != 0; return 0;
         case AOENV_OPT_STORE_ATM_OPD: env->store_opd_atm = value != 0; return 0;
         case AOENV_OPT_FUSED_TAIL: env->use_fused_tail = value != 0; return 0;
+        case AOENV_OPT_FUSED_STEP: env->use_fused_step = value != 0; return 0;
         case 99: env->debug_ablate = value; return 0;
         default: return fail("unknown option %d", option);
     }

@@ -203,6 +203,7 @@ __global__ void __launch_bounds__(256) k_recon_finish(const FinishArgs<T> f) {
     __syncthreads();
     if (threadIdx.x == 0) {
         if (f.reward) f.reward[e] = (T)(-sqrt(red[0] + red[1] + red[2] + red[3]));
+        if (f.ret && f.do_integrate) f.ret[e] += (T)(-sqrt(red[0] + red[1] + red[2] + red[3]));
         // telemetry from the phase kernel's per-tile sums (fixed order): std(OPD[pupil]) * 1e9, exp(-var(phase[pupil]))
         double v[4] = {0, 0, 0, 0};
         const double* pp = f.part + (size_t)e * f.n_tiles * 4;

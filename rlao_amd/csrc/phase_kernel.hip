@@ -25,15 +25,6 @@ namespace ao {
 
 constexpr int kTY = 16, kTXmax = 128;
 
-template <typename T>
-struct KArgs {
-    PhaseArgs pa;
-    PhaseBuffers<T> pb;
-    int R, n_act, n_valid_act, tx, rp, ablate;
-    T atm_scale;   // lambda_atm / 2 pi
-    T src_scale;   // 2 pi / lambda_src
-};
-
 __device__ inline double wave_sum(double v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
     return v;
@@ -385,8 +376,8 @@ int phase_tiles(int R) {
 }
 
 template <typename T>
-int launch_phase(const PhaseArgs& pa, const PhaseBuffers<T>& pb, int n_env, int R, int n_act, int n_valid_act,
-                 double atm_wavelength, double src_wavelength, int use_mfma, hipStream_t st) {
+KArgs<T> make_phase_kargs(const PhaseArgs& pa, const PhaseBuffers<T>& pb, int R, int n_act, int n_valid_act,
+                          double atm_wavelength, double src_wavelength) {
     KArgs<T> a;
     a.pa = pa;
     a.pb = pb;
@@ -395,9 +386,19 @@ int launch_phase(const PhaseArgs& pa, const PhaseBuffers<T>& pb, int n_env, int 
     a.n_valid_act = n_valid_act;
     a.tx = R < kTXmax ? R : kTXmax;
     a.rp = cdiv(R, kTXmax) * kTXmax;
-    a.ablate = use_mfma >> 8;                      // diagnostic builds only (bench of kernel sections)
+    a.ablate = 0;
     a.atm_scale = (T)(atm_wavelength / 2 / 3.14159265358979323846);
     a.src_scale = (T)(6.283185307179586476925286766559 / src_wavelength);
+    return a;
+}
+template KArgs<float> make_phase_kargs<float>(const PhaseArgs&, const PhaseBuffers<float>&, int, int, int, double, double);
+template KArgs<double> make_phase_kargs<double>(const PhaseArgs&, const PhaseBuffers<double>&, int, int, int, double, double);
+
+template <typename T>
+int launch_phase(const PhaseArgs& pa, const PhaseBuffers<T>& pb, int n_env, int R, int n_act, int n_valid_act,
+                 double atm_wavelength, double src_wavelength, int use_mfma, hipStream_t st) {
+    KArgs<T> a = make_phase_kargs<T>(pa, pb, R, n_act, n_valid_act, atm_wavelength, src_wavelength);
+    a.ablate = use_mfma >> 8;                      // diagnostic builds only (bench of kernel sections)
     if ((use_mfma & 1) && sizeof(T) == 4 && pb.dm_opd == nullptr) {
         // the MFMA kernel tiles with TX = 128 whatever R is (phase_tiles() is the same count for R <= 128 and
         // for R a multiple of 128; otherwise fall through to the generic kernel)

@@ -6,34 +6,9 @@
 //   OOPAO/ShackHartmann.py:314-324  centroid: threshold at thr * max over ALL valid spots, centre of gravity
 //   OOPAO/ShackHartmann.py:583-601  NaN -> 0, reference subtraction, slope units, valid selection
 #include "common.hpp"
+#include "sh_device.hpp"
 
 namespace ao {
-
-template <typename T> struct cplx { T re, im; };
-
-template <typename T> __device__ inline void sincos_t(T x, T* s, T* c);
-template <> __device__ inline void sincos_t<float>(float x, float* s, float* c) { sincosf(x, s, c); }
-template <> __device__ inline void sincos_t<double>(double x, double* s, double* c) { sincos(x, s, c); }
-
-// sin/cos through the hardware v_sin_f32 / v_cos_f32 (argument in revolutions) after a two-constant
-// Cody-Waite reduction to [-pi, pi]: |phase| reaches ~100 rad in open loop, and float32 phase * (1/2pi)
-// alone would lose ~1e-5 rad there.
-__device__ inline void sincos_fast(float x, float* s, float* c) {
-    const float n = rintf(x * 0.15915494309189535f);
-    float r = fmaf(-n, 6.28318548202514648f, x);             // 2 pi rounded to float32 ...
-    r = fmaf(-n, -1.74845553e-07f, r);                       // ... and the remainder of 2 pi
-    const float t = r * 0.15915494309189535f;
-    *s = __builtin_amdgcn_sinf(t);
-    *c = __builtin_amdgcn_cosf(t);
-}
-__device__ inline void sincos_fast(double x, double* s, double* c) { sincos(x, s, c); }
-
-__device__ inline void atomic_max_nonneg(float* addr, float v) {
-    atomicMax(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
-}
-__device__ inline void atomic_max_nonneg(double* addr, double v) {
-    atomicMax(reinterpret_cast<unsigned long long*>(addr), (unsigned long long)__double_as_longlong(v));
-}
 
 // One wavefront per valid lenslet, 4 lenslets per workgroup; grid = (ceil(nValid/4), n_env).
 // The 2-D DFT of the zero-padded field is evaluated as two small dense products restricted to the
@@ -139,20 +114,6 @@ __global__ void __launch_bounds__(256) k_sh_spots(const T* __restrict__ phase, c
 // All arithmetic after stage 0 is register-resident FMAs (~2.6 kFMA per lenslet instead of 5.2 k), and the
 // centring phasor exp(-i pi (n+1)/n (x+y)) = ph_a ph_b is folded into the twiddles.
 // ---------------------------------------------------------------------------------------------------
-namespace fast6 {
-constexpr int P = 6, N = 12, LO = 3, HP = 3, SPW = 21, EST = P * P + 1;
-// cos(k pi / 12), k = 0 .. 23
-__device__ constexpr double kCos[24] = {
-    1.0, 0.96592582628906829, 0.86602540378443865, 0.70710678118654752, 0.5, 0.25881904510252076,
-    0.0, -0.25881904510252076, -0.5, -0.70710678118654752, -0.86602540378443865, -0.96592582628906829,
-    -1.0, -0.96592582628906829, -0.86602540378443865, -0.70710678118654752, -0.5, -0.25881904510252076,
-    0.0, 0.25881904510252076, 0.5, 0.70710678118654752, 0.86602540378443865, 0.96592582628906829};
-// exp(-i pi m / 12)
-__device__ constexpr double cre(int m) { return kCos[((m % 24) + 24) % 24]; }
-__device__ constexpr double cim(int m) { return -kCos[((((m % 24) + 24) % 24) + 18) % 24]; }   // -sin(x) = -cos(x - pi/2)
-// stage-2 twiddle ph_a w^{u(a+lo)} = exp(-i pi (a+lo)(13 + 2u)/12)
-__device__ constexpr int k2(int u, int a) { return (a + LO) * (13 + 2 * u); }
-}  // namespace fast6
 
 template <typename T, bool FAST_TRIG>
 __global__ void __launch_bounds__(128, 2) k_sh_spots_p6(const T* __restrict__ phase, const ShConst<T> sc,
@@ -209,53 +170,7 @@ __global__ void __launch_bounds__(128, 2) k_sh_spots_p6(const T* __restrict__ ph
 #pragma unroll
         for (int u = 0; u < P; ++u) Ia[u] = Ib[u] = (T)0;
         if (ok) {
-            const cplx<T>* Ej = Ew + jl * EST;
-            const T inv_n2 = (T)(1.0 / (N * N));
-            // the two spectral columns v = 2q + c, c = 0, 1 (and their partners v + 6) one after the other:
-            // keeps only 2 x 6 complex G values live (register pressure decides the occupancy here)
-#pragma unroll 1
-            for (int c = 0; c < 2; ++c) {
-                // stage-1 twiddles ph_b w^{(b+lo) v} = exp(-i pi (b+lo)(13 + 2 v)/12) of this lane's column
-                T t1r[P], t1i[P];
-#pragma unroll
-                for (int b = 0; b < P; ++b) {
-                    const int m = ((b + LO) * (13 + 2 * (2 * q + c))) % 24;
-                    t1r[b] = (T)kCos[m];
-                    t1i[b] = (T)(-kCos[(m + 18) % 24]);
-                }
-                T G0r[P], G0i[P], G1r[P], G1i[P];                      // columns v and v + 6
-#pragma unroll
-                for (int a = 0; a < P; ++a) {
-                    T evr = 0, evi = 0, odr = 0, odi = 0;              // b + lo even: b = 1, 3, 5 ; odd: b = 0, 2, 4
-#pragma unroll
-                    for (int b = 0; b < P; ++b) {
-                        const cplx<T> x = Ej[a * P + b];
-                        const T pr = x.re * t1r[b] - x.im * t1i[b];
-                        const T pi = x.re * t1i[b] + x.im * t1r[b];
-                        if ((b + LO) % 2 == 0) { evr += pr; evi += pi; } else { odr += pr; odi += pi; }
-                    }
-                    G0r[a] = evr + odr; G0i[a] = evi + odi;
-                    G1r[a] = evr - odr; G1i[a] = evi - odi;
-                }
-                // stage 2 (compile-time twiddles) + binning; rows u and u + 6 share their products
-#pragma unroll
-                for (int u = 0; u < P; ++u) {
-                    T e0r = 0, e0i = 0, o0r = 0, o0i = 0, e1r = 0, e1i = 0, o1r = 0, o1i = 0;
-#pragma unroll
-                    for (int a = 0; a < P; ++a) {
-                        const T kr = (T)cre(k2(u, a)), ki = (T)cim(k2(u, a));
-                        const T p0r = G0r[a] * kr - G0i[a] * ki, p0i = G0r[a] * ki + G0i[a] * kr;
-                        const T p1r = G1r[a] * kr - G1i[a] * ki, p1i = G1r[a] * ki + G1i[a] * kr;
-                        if ((a + LO) % 2 == 0) { e0r += p0r; e0i += p0i; e1r += p1r; e1i += p1i; }
-                        else { o0r += p0r; o0i += p0i; o1r += p1r; o1i += p1i; }
-                    }
-                    T fr_, fi_;
-                    fr_ = e0r + o0r; fi_ = e0i + o0i; Ia[u / 2] += (fr_ * fr_ + fi_ * fi_) * inv_n2;        // (u, v)
-                    fr_ = e0r - o0r; fi_ = e0i - o0i; Ia[u / 2 + 3] += (fr_ * fr_ + fi_ * fi_) * inv_n2;    // (u+6, v)
-                    fr_ = e1r + o1r; fi_ = e1i + o1i; Ib[u / 2] += (fr_ * fr_ + fi_ * fi_) * inv_n2;        // (u, v+6)
-                    fr_ = e1r - o1r; fi_ = e1i - o1i; Ib[u / 2 + 3] += (fr_ * fr_ + fi_ * fi_) * inv_n2;    // (u+6, v+6)
-                }
-            }
+            lenslet_spots<T>(Ew + jl * EST, q, Ia, Ib);
 #pragma unroll
             for (int u = 0; u < P; ++u) {
                 mx = Ia[u] > mx ? Ia[u] : mx;
@@ -436,74 +351,7 @@ __global__ void __launch_bounds__(1024) k_sh_tail(const T* __restrict__ frame, c
         }
     }
     __syncthreads();
-    // ---- t = M s -------------------------------------------------------------------------------------------------------
-    const int n_sig = 2 * n_valid, A = f.n_valid_act;
-    T* tm = img_s + img;                                        // [K] modal coefficients
-    for (int k0 = 0; k0 < n_modes; k0 += (int)blockDim.x / 16) {
-        const int k = k0 + tid / 16, l16 = tid & 15;
-        T acc = 0;
-        if (k < n_modes) {
-            const T* row = fac_m + (size_t)k * n_sig;
-#pragma unroll 4
-            for (int q = l16; q < n_sig; q += 16) acc += row[q] * sl[q];
-        }
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 16);
-        if (k < n_modes && l16 == 0) tm[k] = acc;
-    }
-    __syncthreads();
-    // ---- o = -M2C t, integrator, image ---------------------------------------------------------------------------------
-    double ss = 0.0;
-    for (int k = tid; k < A; k += blockDim.x) {
-        T acc = 0;
-        const T* col = fac_m2c_t + k;
-#pragma unroll 10
-        for (int q = 0; q < n_modes; ++q) acc += col[(size_t)q * A] * tm[q];
-        const int px = f.act_idx[k];
-        T* ob = f.obs + (size_t)e * img;
-        if (f.do_integrate) {
-            const T act = (f.gain_from_obs != (T)0) ? f.gain_from_obs * ob[px] : f.action[(size_t)e * img + px];
-            T* c = f.coefs + (size_t)e * A + k;
-            const float af = (float)act;                          // float32 increment, see k_recon_finish
-            const T inc = ((T)af == act) ? (T)(af * 1e-6f) : act * (T)1e-6;
-            *c = (*c) * f.leak + inc;
-        }
-        const T o = -acc * (T)1e6;
-        img_s[px] = o;
-        ss += (double)o * (double)o;
-    }
-    __syncthreads();
-    T* ob = f.obs + (size_t)e * img;
-    for (int q = tid; q < img; q += blockDim.x) ob[q] = img_s[q];
-    for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off);
-    if ((tid & (kWave - 1)) == 0) red[tid / kWave] = ss;
-    __syncthreads();
-    if (tid == 0) {
-        double tot = 0;
-        for (int q = 0; q < (int)blockDim.x / kWave; ++q) tot += red[q];
-        if (f.reward) f.reward[e] = (T)(-sqrt(tot));
-        double v[4] = {0, 0, 0, 0};
-        const double* pp = f.part + (size_t)e * f.n_tiles * 4;
-        for (int t = 0; t < f.n_tiles; ++t)
-            for (int k = 0; k < 4; ++k) v[k] += pp[t * 4 + k];
-        const double n = (double)f.n_pupil;
-        double var_atm = v[1] / n - (v[0] / n) * (v[0] / n);
-        double var_res = v[3] / n - (v[2] / n) * (v[2] / n);
-        var_atm = var_atm > 0 ? var_atm : 0;
-        var_res = var_res > 0 ? var_res : 0;
-        const double total = sqrt(var_atm) * 1e9, resid = sqrt(var_res) * 1e9;
-        const double sr = exp(-var_res * f.src_scale * f.src_scale);
-        T* scp = f.scal + 4 * e;
-        scp[0] = (T)total;
-        scp[1] = (T)resid;
-        scp[2] = (T)sr;
-        if (f.strehl) f.strehl[e] = (T)sr;
-        if (f.telemetry_index >= 0) {
-            const size_t o = (size_t)f.telemetry_index * n_env + e;
-            f.total[o] = (T)total;
-            f.residual[o] = (T)resid;
-        }
-    }
+    tail_from_slopes<T>(sl, img_s, red, fac_m, fac_m2c_t, n_modes, f, e, n_valid, n_env);
 }
 
 template <typename T>

@@ -1,0 +1,428 @@
+// The whole env.step() of one AO loop in ONE workgroup: one launch per step, one workgroup (16 waves) per env.
+//
+//   MAIN/OOPAOEnv/OOPAOEnv.py:485-536 (step)  =  atmosphere sub-pixel translation + footprint + layer sum
+//   (OOPAO/Atmosphere.py:406-407, 439-450, 474-477)  ->  DM surface and residual phase (DeformableMirror.py:556, 469;
+//   Telescope.py:404-412, 540-542)  ->  Shack-Hartmann spots, camera frame, thresholded centre of gravity, slopes
+//   (ShackHartmann.py:340-347, 539-601)  ->  reconstruction, reward, leaky integrator, Strehl / rms telemetry
+//   (OOPAOEnv.py:491-536).
+//
+// Why one workgroup per env: at the BASELINE sizes (R = 120: 57.6 KB of phase, 316 valid lenslets) every intermediate
+// of an env fits in the 160 KB of LDS of one CU, so the residual phase never has to be re-read from HBM by the WFS,
+// the camera frame never by the centroid, and the five dependent launches of the separate-kernel path (each mostly
+// launch + memory latency at a few hundred envs) collapse into one.  256 envs = one workgroup on each of the 256 CUs.
+//
+//   stage A (2 passes of 64 rows): layer tile -> LDS, separable Catmull-Rom, DM surface s1 . Gx^T on the matrix
+//            cores (v_mfma_f32_16x16x4_f32, whose output layout is the lane -> pixel map), pupil, phase store,
+//            E0 = amp e^{i phi} parked in LDS per lenslet, float64 telemetry sums
+//   stage B  3 lanes per valid lenslet (948 of 1024 lanes at 316 lenslets): register-resident 12 x 12 DFT + 2 x 2
+//            binning (sh_device.hpp), frame store, workgroup max -> threshold -> centre of gravity in registers
+//   stage C  t = M s, o = -M2C t, integrator, observation image, reward, telemetry (tail_from_slopes)
+//
+// Arithmetic is the same as in the separate kernels (phase_kernel.hip, sh_kernels.hip); only summation orders of the
+// centroid and of the telemetry differ (float32 / float64 rounding level).  No atomics: bitwise reproducible.
+#include "common.hpp"
+
+// Diagnostic build only (-DAO_STEP_STAMPS): wave 0 of each workgroup stamps s_memtime at the stage boundaries.
+#ifdef AO_STEP_STAMPS
+namespace ao { __device__ unsigned long long g_stamps[1024 * 24]; }
+#define AO_STAMP(i) do { if (tid == 0 && e < 1024) ::ao::g_stamps[e * 24 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define AO_STAMP(i) do { } while (0)
+#endif
+
+#include "sh_device.hpp"
+
+namespace ao {
+
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+
+// p[idx] if ok else 0, as an UNCONDITIONAL load from a clamped (always valid) index: a predicated load compiles to a
+// branch around the load, and a run of them to a chain of dependent memory latencies.
+template <typename P>
+__device__ inline float ld_or0(const P* __restrict__ p, long idx, bool ok) {
+    const float v = (float)p[ok ? idx : 0];
+    return ok ? v : 0.f;
+}
+
+namespace fstep {
+constexpr int TX = 128, MW = TX + 4, PR = 64;          // tile width, staged row stride, rows per pass
+constexpr int MW4 = MW / 4;                            // float4 per staged row
+constexpr int NV4 = ((PR + 3) * MW4 + 1023) / 1024;    // 16-byte staging loads per lane and layer
+}  // namespace fstep
+
+struct StepLds {
+    int cimg, s1, mapt, slot, e0, sl, img, total;      // offsets in 4-byte words
+};
+
+static StepLds step_lds_layout(int n_act, int n_subap, int n_valid, int n_modes) {
+    using namespace fstep;
+    StepLds L;
+    const int nAp = (n_act + 3) & ~3, SS = nAp + 1;
+    int o = 0;
+    auto take = [&](int words) { const int at = o; o += (words + 3) & ~3; return at; };
+    L.cimg = take(n_act * n_act);
+    L.s1 = take(2 * PR * SS);
+    L.mapt = take((PR + 3) * MW);
+    L.slot = take((n_subap * n_subap + 1) / 2);
+    L.e0 = take(2 * n_valid * fast6::EST);
+    L.sl = take(2 * n_valid);
+    L.img = take(n_act * n_act + n_modes);
+    L.total = o;
+    return L;
+}
+
+// KS: k steps (of 4) of the DM product whose B operands are held in registers, n_act <= 4 KS
+template <int KS>
+__global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const StepLds L) {
+    using namespace fstep;
+    using fast6::EST;
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    float* lds = reinterpret_cast<float*>(lds_raw);
+    const KArgs<float>& k = a.k;
+    const int R = k.R, nA = k.n_act, S = k.pa.S;
+    const int nAp = (nA + 3) & ~3, SS = nAp + 1;
+    float* cimg = lds + L.cimg;                                  // [nA][nA] command image
+    float* s1 = lds + L.s1;                                      // [2 PR][SS]  Gy C, every row
+    float* mapt = lds + L.mapt;                                  // [PR + 3][MW] staged layer tile (also the Gy rows)
+    short* slot_s = reinterpret_cast<short*>(lds + L.slot);      // [nSub^2] lenslet -> compact valid index or -1
+    cplx<float>* E0 = reinterpret_cast<cplx<float>*>(lds + L.e0);    // [nValid][EST]
+    float* sl = lds + L.sl;                                      // [2 nValid] slopes
+    float* img_s = lds + L.img;                                  // [nA^2 + n_modes]
+    __shared__ double red[4][16];
+    __shared__ double red_tail[16];
+    __shared__ float red_mx[16];
+
+    const int e = blockIdx.x;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int lc = lane & 15, lq = lane >> 4;                    // MFMA lane decomposition
+    const int band = w >> 2, cg = w & 3;                         // 16-row band of the pass, 32-column group
+    const size_t pix0 = (size_t)e * R * R;
+    const int n_sub = a.n_subap, n_valid = a.n_valid;
+
+    AO_STAMP(0);
+    // ---- prologue: every global load of the prologue is issued before the first barrier ------------------------------------
+    // (the barriers are compiler fences for memory operations: a load written after one is issued after it)
+    // A operands of the DM product, Gx[x][k = lane >> 4 + 4 step]: the lane's two column tiles are the same in every
+    // pass, so they are loaded once, long before the matrix cores need them.  The host re-lays the influence factors
+    // out as ga[x][lane >> 4][step] (8 floats per entry), so a lane's 6..8 values are two 16-byte loads, not 6..8 dwords.
+    f32x4s gx_raw[2][2], gy_raw[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const f32x4s* src = reinterpret_cast<const f32x4s*>(a.gxa + ((size_t)(16 * (2 * cg + tt) + lc) * 4 + lq) * 8);
+        gx_raw[tt][0] = src[0];
+        gx_raw[tt][1] = src[1];
+    }
+    const int rt = w >> 1, ct = w & 1;                           // s1 tile of this wave: rows 16 rt.., command columns 16 ct..
+    {
+        const f32x4s* src = reinterpret_cast<const f32x4s*>(a.gya + ((size_t)(16 * rt + lc) * 4 + lq) * 8);   // gy[row][lq + 4 step]
+        gy_raw[0] = src[0];
+        gy_raw[1] = src[1];
+    }
+    const bool has_act = tid < k.n_valid_act;                    // n_valid_act <= 1024 (n_act <= 32)
+    const int act_px = k.pb.act_idx[has_act ? tid : 0];
+    const float act_c = k.pb.coefs[(size_t)e * k.n_valid_act + (has_act ? tid : 0)];
+    const short slot_v = a.slot_of[tid < n_sub * n_sub ? tid : 0];
+    for (int i = tid; i < nA * nA; i += 1024) cimg[i] = 0.f;
+    for (int i = tid; i < nA * nA; i += 1024) img_s[i] = 0.f;
+    for (int i = tid; i < 2 * PR * SS; i += 1024) s1[i] = 0.f;
+    if (tid < n_sub * n_sub) slot_s[tid] = slot_v;
+    for (int i = tid + 1024; i < n_sub * n_sub; i += 1024) slot_s[i] = a.slot_of[i];
+    lds_barrier();
+    if (has_act) cimg[act_px] = act_c;
+    float breg[2][KS];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const float t[8] = {gx_raw[tt][0][0], gx_raw[tt][0][1], gx_raw[tt][0][2], gx_raw[tt][0][3],
+                            gx_raw[tt][1][0], gx_raw[tt][1][1], gx_raw[tt][1][2], gx_raw[tt][1][3]};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) breg[tt][ks] = t[ks];
+    }
+
+    // ---- s1[y][ix] = sum_iy gy[y][iy] C[iy][ix] for every row, on the matrix cores: 8 x 2 tiles of 16 x 16, one per wave ---
+    lds_barrier();                                             // cimg complete
+    {
+        const int ix = 16 * ct + lc;
+        float av[KS], bv[KS];
+        {
+            const float t[8] = {gy_raw[0][0], gy_raw[0][1], gy_raw[0][2], gy_raw[0][3], gy_raw[1][0], gy_raw[1][1], gy_raw[1][2], gy_raw[1][3]};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) av[ks] = t[ks];                                   // A[i = lane & 15][k = lane >> 4]
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int iy = lq + 4 * ks;
+            bv[ks] = ld_or0(cimg, iy * nA + ix, iy < nA && ix < nA);                      // B[k = lane >> 4][j = lane & 15]
+        }
+        f32x4s d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bv[ks], d, 0, 0, 0);
+        if (ix < nA) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s1[(16 * rt + 4 * lq + r) * SS + ix] = d[r];
+        }
+    }
+
+    // Lane -> pixel map of a pass (64 rows): wave = (band = w >> 2: 16 rows, cg = w & 3: 32 columns = 2 tiles of 16);
+    // in a tile the lane owns ONE row y = 16 band + (lane & 15) and FOUR CONSECUTIVE columns x = 16 tile + 4 (lane >> 4) + r.
+    // That is the output layout of the matrix cores for D[x][y] = sum_k Gx^T[k][x] s1[y][k] (rows 4 (lane >> 4) + r = x,
+    // column lane & 15 = y), and it makes every global access of the pass a 16-byte one (the vector-memory path takes
+    // ~16 cycles per wave-instruction whatever the width: dword accesses were 3/4 of this kernel's time).
+    double s_atm = 0.0, q_atm = 0.0, s_res = 0.0, q_res = 0.0;
+    for (int pass = 0; pass < (R + PR - 1) / PR; ++pass) {
+        const int y0 = pass * PR;
+        const int tye = min(PR, R - y0);
+        const int yl = 16 * band + lc, y = y0 + yl;              // the lane's row
+        const bool row_ok = yl < tye;
+        lds_barrier();                                           // s1 complete / previous pass done with mapt
+        AO_STAMP(1 + 6 * pass);
+        // pupil + WFS amplitude of the lane's 2 x 4 pixels (one table: amplitude, or -1 outside the pupil), long before use
+        f32x4s apv[2];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int x = 16 * (2 * cg + tt) + 4 * lq;
+            const bool okp = row_ok && x < R;
+            apv[tt] = *reinterpret_cast<const f32x4s*>(a.amp_pupil + (okp ? (size_t)y * R + x : 0));
+            if (!okp) apv[tt] = f32x4s{-1.f, -1.f, -1.f, -1.f};
+        }
+
+        // ---- atmosphere: every layer's tile through LDS (16-byte loads), separable Catmull-Rom ----------------------------
+        f32x4s sup[2];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) sup[tt] = f32x4s{0.f, 0.f, 0.f, 0.f};
+        for (int l = 0; l < k.pa.n_layer; ++l) {
+            const LayerTaps& tp = k.pa.taps[l];
+            const float* map = static_cast<const float*>(k.pa.screen[l]) + (size_t)e * S * S;
+            const int r0 = y0 + k.pa.foot + tp.dy - 1, c0 = k.pa.foot + tp.dx - 1;
+            lds_barrier();                                       // the previous layer's tile is no longer read
+            AO_STAMP(3 + 6 * pass);
+            {
+                // tile element (r, c) = map[r0 + r][c0 + c], r < tye + 3, c < R + 3; staged as rows of MW4 float4
+                f32x4s v[NV4];
+#pragma unroll
+                for (int q = 0; q < NV4; ++q) {
+                    const int idx = tid + 1024 * q;
+                    const int r = idx / MW4, c = 4 * (idx - r * MW4);
+                    const int rr = r0 + r, cc = c0 + c;
+                    const bool ok = idx < (PR + 3) * MW4 && r < tye + 3 && c < R + 3 && rr >= 0 && rr < S && cc >= 0 && cc + 3 < S;
+                    const float* src = map + (ok ? (size_t)rr * S + cc : 0);
+                    f32x4s t;                                     // the screen rows are only 4-byte aligned (S = R + 6)
+                    __builtin_memcpy(&t, src, 16);
+                    v[q] = ok ? t : f32x4s{0.f, 0.f, 0.f, 0.f};
+                    if (!ok && idx < (PR + 3) * MW4 && r < tye + 3 && c < R + 3 && rr >= 0 && rr < S) {
+                        // a float4 that straddles the right edge of the screen: element by element (never at S = R + 6)
+                        for (int d = 0; d < 4; ++d)
+                            if (cc + d >= 0 && cc + d < S) v[q][d] = map[(size_t)rr * S + cc + d];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < NV4; ++q) {
+                    const int idx = tid + 1024 * q;
+                    if (idx < (PR + 3) * MW4) *reinterpret_cast<f32x4s*>(mapt + 4 * idx) = v[q];
+                }
+            }
+            lds_barrier();
+            AO_STAMP(4 + 6 * pass);
+            const float wx0 = (float)tp.wx[0], wx1 = (float)tp.wx[1], wx2 = (float)tp.wx[2], wx3 = (float)tp.wx[3];
+            const float wy0 = (float)tp.wy[0], wy1 = (float)tp.wy[1], wy2 = (float)tp.wy[2], wy3 = (float)tp.wy[3];
+            const float* mm = static_cast<const float*>(k.pa.minmax[l]) + 2 * e;
+            const float lo = mm[0], hi = mm[1], wl = (float)tp.weight;
+            const bool zero_outside = (lo > 0.f || hi < 0.f);
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const int xt = 16 * (2 * cg + tt) + 4 * lq;       // tile column of the first tap of the lane's first pixel
+                // the 4 rows x 8 columns of taps (7 used) as 16-byte LDS reads; horizontal pass per row, then vertical
+                float h[4][4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float* m = mapt + (yl + q) * MW + xt;
+                    const f32x4s m0 = *reinterpret_cast<const f32x4s*>(m), m1 = *reinterpret_cast<const f32x4s*>(m + 4);
+                    const float t[7] = {m0[0], m0[1], m0[2], m0[3], m1[0], m1[1], m1[2]};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h[q][r] = ((wx0 * t[r] + wx1 * t[r + 1]) + wx2 * t[r + 2]) + wx3 * t[r + 3];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = ((wy0 * h[0][r] + wy1 * h[1][r]) + wy2 * h[2][r]) + wy3 * h[3][r];
+                    // skimage clip=True: clamp to the input range, keep exact zeros when 0 is outside it
+                    if (!(zero_outside && v == 0.f)) v = v < lo ? lo : (v > hi ? hi : v);
+                    sup[tt][r] += v * wl;
+                }
+            }
+        }
+        lds_barrier();                                           // (only needed when there is no layer)
+        AO_STAMP(5 + 6 * pass);
+
+        // ---- DM surface on the matrix cores, pupil, phase store, E0 -> LDS, telemetry sums -----------------------------
+        const int iy = y / 6, by = y - 6 * iy;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int x = 16 * (2 * cg + tt) + 4 * lq;
+            f32x4s dmv = {0.f, 0.f, 0.f, 0.f};
+            const float* bp = s1 + (size_t)(row_ok ? y : 0) * SS + lq;   // B[k = lane >> 4][j = lane & 15 -> row y]   (LDS)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)                              // A[i = lane & 15 -> column][k = lane >> 4] = breg
+                if (4 * ks < nAp) dmv = __builtin_amdgcn_mfma_f32_16x16x4f32(breg[tt][ks], bp[4 * ks], dmv, 0, 0, 0);
+            if (row_ok && x < R) {
+                const size_t q = (size_t)y * R + x;
+                f32x4s atm, phi;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    atm[r] = sup[tt][r] * k.atm_scale;
+                    const bool in = apv[tt][r] >= 0.f;
+                    const float res = in ? (atm[r] + dmv[r]) : 0.f;
+                    phi[r] = res * k.src_scale;
+                    if (in) {
+                        const double da = (double)atm[r], dr = (double)res;
+                        s_atm += da;
+                        q_atm += da * da;
+                        s_res += dr;
+                        q_res += dr * dr;
+                    }
+                }
+                if (k.pa.store_atm) *reinterpret_cast<f32x4s*>(k.pb.opd_atm + pix0 + q) = atm;
+                *reinterpret_cast<f32x4s*>(k.pb.phase + pix0 + q) = phi;
+                // lenslet (i, j) element E[a][b] = phase[i p + b][j p + a]: the reference tiles phase.T
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int jx = (x + r) / 6, ax = (x + r) - 6 * jx;
+                    const int slot = slot_s[iy * n_sub + jx];
+                    if (slot >= 0) {                                      // every pixel of a valid lenslet, lit or not
+                        const float am = apv[tt][r] >= 0.f ? apv[tt][r] * (1.f / 12.f) : 0.f;   // 1/n of |FFT2(E)/n|^2 (ShackHartmann.py:539)
+                        float sn = 0.f, cs = 0.f;
+                        if (am != 0.f) {
+                            if (a.sc.fast_trig) sincos_fast(phi[r], &sn, &cs); else sincosf(phi[r], &sn, &cs);
+                        }
+                        E0[slot * EST + ax * 6 + by] = {am * cs, am * sn};
+                    }
+                }
+            }
+        }
+    }
+    AO_STAMP(13);
+    // telemetry: waves in a fixed order
+    s_atm = wave_sum_f64(s_atm);
+    q_atm = wave_sum_f64(q_atm);
+    s_res = wave_sum_f64(s_res);
+    q_res = wave_sum_f64(q_res);
+    if (lane == 0) {
+        red[0][w] = s_atm;
+        red[1][w] = q_atm;
+        red[2][w] = s_res;
+        red[3][w] = q_res;
+    }
+    lds_barrier();                                             // E0 complete, red complete
+    AO_STAMP(14);
+    if (tid == 1023) {                                           // an idle lane: runs beside the spots of the other waves
+        double v[4];
+        for (int c = 0; c < 4; ++c) {
+            double t = 0;
+            for (int q = 0; q < 16; ++q) t += red[c][q];
+            v[c] = t;
+        }
+        double* pp = k.pb.part + (size_t)e * 4;                  // kept for state inspection (FinishArgs.n_tiles == 1)
+        for (int c = 0; c < 4; ++c) pp[c] = v[c];
+        telemetry_scalars<float>(a.fa, e, a.n_env, v);
+    }
+
+    // ---- stage B: spots, frame, threshold, centre of gravity ---------------------------------------------------------------
+    const int sl_i = lane / 3, q3 = lane - 3 * sl_i;
+    const int s = 21 * w + sl_i;
+    const bool ok = lane < 63 && s < n_valid;
+    float Ia[6], Ib[6];
+#pragma unroll
+    for (int u = 0; u < 6; ++u) Ia[u] = Ib[u] = 0.f;
+    float mx = 0.f;
+    int li = 0, lj = 0;
+    if (ok) {
+        fast6::lenslet_spots<float, 2, true>(E0 + s * EST, q3, Ia, Ib);
+        const int kk = a.sc.subap_idx[s];
+        li = kk / n_sub;
+        lj = kk - li * n_sub;
+        float* fr = a.frame + pix0 + (size_t)(li * 6) * R + lj * 6 + q3;
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            fr[(size_t)u * R] = Ia[u];
+            fr[(size_t)u * R + 3] = Ib[u];
+            mx = Ia[u] > mx ? Ia[u] : mx;
+            mx = Ib[u] > mx ? Ib[u] : mx;
+        }
+    }
+    AO_STAMP(15);
+    for (int off = 32; off > 0; off >>= 1) {
+        const float o = __shfl_down(mx, off);
+        mx = o > mx ? o : mx;
+    }
+    if (lane == 0) red_mx[w] = mx;
+    lds_barrier();
+    AO_STAMP(16);
+    mx = red_mx[0];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) mx = red_mx[q] > mx ? red_mx[q] : mx;
+    if (tid == 0) a.wfs_max[e] = mx;
+    const float cut = a.sc.threshold * mx;
+    {
+        float norm = 0.f, m0 = 0.f, m1 = 0.f;
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const float xa = Ia[u] < cut ? 0.f : Ia[u], xb = Ib[u] < cut ? 0.f : Ib[u];
+            const float rs = xa + xb;
+            norm += rs;
+            m0 += rs * (float)u;
+            m1 += xa * (float)q3 + xb * (float)(q3 + 3);
+        }
+        norm += __shfl_down(norm, 1) + __shfl_down(norm, 2);
+        m0 += __shfl_down(m0, 1) + __shfl_down(m0, 2);
+        m1 += __shfl_down(m1, 1) + __shfl_down(m1, 2);
+        if (ok && q3 == 0) {
+            float c0 = 0.f, c1 = 0.f;
+            if (norm != 0.f) {
+                c0 = m0 / norm;
+                c1 = m1 / norm;
+            }
+            const float v0 = (c0 - a.sc.ref[s]) / a.sc.units, v1 = (c1 - a.sc.ref[n_valid + s]) / a.sc.units;
+            sl[s] = v0;
+            sl[n_valid + s] = v1;
+            a.signal[(size_t)e * 2 * n_valid + s] = v0;
+            a.signal[(size_t)e * 2 * n_valid + n_valid + s] = v1;
+        }
+    }
+    lds_barrier();
+    AO_STAMP(17);
+
+    // ---- stage C ------------------------------------------------------------------------------------------------------------
+    tail_from_slopes<float, false>(sl, img_s, red_tail, a.fac_m, a.fac_m2c_t, a.n_modes, a.fa, e, n_valid, a.n_env);
+    AO_STAMP(18);
+}
+
+#ifdef AO_STEP_STAMPS
+extern "C" int aoenv_debug_stamps(unsigned long long* h_out, int n_env) {
+    return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 24 * (size_t)n_env) == hipSuccess ? 0 : 1;
+}
+#endif
+
+int step_fused_supported(int R, int n_subap, int n_valid, int n_act, int n_modes) {
+    if (R % n_subap || R / n_subap != fast6::P) return 0;
+    if (R > fstep::TX || R % 4) return 0;
+    if (n_valid > 16 * 21 || n_subap * n_subap > 32767 || n_act > 32) return 0;
+    if (n_modes < 1) return 0;
+    const StepLds L = step_lds_layout(n_act, n_subap, n_valid, n_modes);
+    return (size_t)L.total * 4 <= 160 * 1024 - 1024 ? 1 : 0;     // static __shared__ of the kernel: < 1 KB
+}
+
+int launch_env_step(const StepArgs& a, hipStream_t st) {
+    const StepLds L = step_lds_layout(a.k.n_act, a.n_subap, a.n_valid, a.n_modes);
+    const size_t lds = (size_t)L.total * 4;
+    static size_t attr_set[2] = {0, 0};
+    const int v = a.k.n_act <= 24 ? 0 : 1;
+    const void* fn = v == 0 ? reinterpret_cast<const void*>(k_env_step_sh6<6>) : reinterpret_cast<const void*>(k_env_step_sh6<8>);
+    if (lds > 64 * 1024 && lds > attr_set[v]) {
+        AO_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set[v] = lds;
+    }
+    if (v == 0) hipLaunchKernelGGL(k_env_step_sh6<6>, dim3(a.n_env), dim3(1024), lds, st, a, L);
+    else hipLaunchKernelGGL(k_env_step_sh6<8>, dim3(a.n_env), dim3(1024), lds, st, a, L);
+    AO_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace ao

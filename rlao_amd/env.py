@@ -642,6 +642,16 @@ class BatchedAOEnv:
             C.c_void_p(self._reward.data_ptr()), C.c_void_p(self._strehl.data_ptr()), C.c_void_p(self._stream())))
         return self._obs, self._reward, self._strehl
 
+    def accumulate_returns(self, tensor):
+        """Attach a device tensor [n_envs] (env dtype) to which every step adds its reward (None detaches): the
+        episode return the trainers sum on the host (MAIN/PO4AO/mbrl.py:64-89), kept on the device."""
+        if tensor is not None:
+            if tuple(tensor.shape) != (self.n_envs,) or tensor.dtype != self.tdtype or not tensor.is_cuda or not tensor.is_contiguous():
+                raise ValueError(f"the return accumulator must be a contiguous cuda {self.tdtype} tensor of shape ({self.n_envs},)")
+        self._returns = tensor
+        L.check(self._shard.lib.aoenv_set_return_accumulator(
+            self._shard.h, None if tensor is None else C.c_void_p(tensor.data_ptr())))
+
     def calculate_strehl_AVG(self):
         """MAIN/OOPAOEnv/OOPAOEnv.py:538-546: (mean, std) over the episode, then clears the list."""
         torch = _torch()
