@@ -20,7 +20,7 @@ WFS_SH, WFS_PYRAMID = 0, 1
 
 
 OPT_FAST_WFS, OPT_MFMA_GEMM, OPT_FAST_TRIG, OPT_STORE_ATM_OPD, OPT_FUSED_TAIL, OPT_FUSED_STEP = 0, 1, 2, 3, 4, 5
-KERNEL_NAMES = ("shift_gather", "mt_normal", "gemm_ring", "scatter_minmax", "phase", "sh_spots", "sh_centroid",
+KERNEL_NAMES = ("ring_prepare", "mt_normal", "gemm_ring", "ring_scatter", "phase", "sh_spots", "sh_centroid",
                 "gemm_recon", "recon_finish", "pyramid", "sh_tail", "env_step")
 
 

@@ -7,42 +7,29 @@ namespace ao {
 // ---------------------------------------------------------------------------------------------------
 // add_row, part 1: onePixelShiftedPhaseScreen = warp(map_full, translate(sx, sy))[1:-1, 1:-1]  and
 // Z = shifted[innerMask].  A one-pixel translation through the cubic interpolator returns the source
-// pixel exactly, so the shift is a strided copy  new[r][c] = old[r - sy][c - sx]  of the N x N interior;
-// no interior pixel reads outside the (N+2)^2 map.  The copy goes to the other half of a ping-pong pair
-// (in-place would race).  Z is gathered straight from the OLD map (idx - sy*S - sx), so the two loops
-// are independent.  grid = (chunks, n_env); lanes walk rows contiguously (coalesced 4/8-byte accesses).
+// pixel exactly: new[r][c] = old[r - sy][c - sx] on the N x N interior, and no interior pixel reads
+// outside the (N+2)^2 map.  The screen is therefore kept as a TORUS: logical pixel (r, c) lives at
+// physical ((r + oy) mod S, (c + ox) mod S), and the shift only moves the origin (oy, ox) -> (oy - sy,
+// ox - sx); the old border row / column that wraps around becomes the new border, which the ring
+// extrusion overwrites anyway.  No pixel is copied (the copy was as much HBM traffic as the step itself).
+// Here only Z = old_logical[r_k - sy][c_k - sx] is gathered, through the OLD origin.
 // ---------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ void __launch_bounds__(256) k_shift_gather(const T* __restrict__ old_map, T* __restrict__ new_map,
-                                                      T* __restrict__ zx, const int* __restrict__ inner_idx, int S,
-                                                      int n_inner, int K, int sx, int sy, int do_copy) {
-    const int e = blockIdx.y;
-    const size_t base = (size_t)e * S * S;
-    const T* src = old_map + base;
-    const int shift = sy * S + sx;
-    if (do_copy) {
-        T* dst = new_map + base;
-        const int N = S - 2;
-        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N * N; i += gridDim.x * blockDim.x) {
-            const int r = i / N + 1, c = i % N + 1;
-            dst[r * S + c] = src[r * S + c - shift];
-        }
-    }
-    if (blockIdx.x == 0) {
-        for (int k = threadIdx.x; k < n_inner; k += blockDim.x) zx[(size_t)e * K + k] = src[inner_idx[k] - shift];
-    }
+__device__ inline int torus(int r, int c, int oy, int ox, int S) {
+    int pr = r + oy, pc = c + ox;
+    pr = pr >= S ? pr - S : pr;
+    pc = pc >= S ? pc - S : pc;
+    return pr * S + pc;
 }
 
 template <typename T>
-int launch_shift_gather(const T* old_map, T* new_map, T* zx, const int* inner_idx, int n_env, int S, int n_inner,
-                        int K, int sx, int sy, int do_copy, hipStream_t st) {
-    const int N = S - 2;
-    int chunks = do_copy ? cdiv(N * N, 256 * 8) : 1;
-    dim3 grid(chunks, n_env);
-    hipLaunchKernelGGL(k_shift_gather<T>, grid, dim3(256), 0, st, old_map, new_map, zx, inner_idx, S, n_inner, K, sx,
-                       sy, do_copy);
-    AO_HIP(hipGetLastError());
-    return 0;
+__device__ inline void gather_ring(const T* __restrict__ map, T* __restrict__ zx, const int* __restrict__ inner_idx, int S,
+                                   int n_inner, int K, int sx, int sy, int oy, int ox, int e, int t0, int nt) {
+    const T* src = map + (size_t)e * S * S;
+    for (int k = t0; k < n_inner; k += nt) {
+        const int idx = inner_idx[k];
+        const int r = idx / S - sy, c = idx % S - sx;            // interior pixel: 0 <= r, c < S
+        zx[(size_t)e * K + k] = src[torus(r, c, oy, ox, S)];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -90,12 +77,11 @@ __device__ inline void mt_twist(uint32_t* s) {
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256) k_mt_normal(uint32_t* __restrict__ mt_state, int* __restrict__ mt_pos,
-                                                   T* __restrict__ zx, int K, int n_inner, int n_outer) {
+__device__ inline void mt_normal_body(uint32_t* __restrict__ mt_state, int* __restrict__ mt_pos, T* __restrict__ zx, int K,
+                                      int n_inner, int n_outer, int e) {
     __shared__ uint32_t s[kMtN];
     __shared__ int scan[256];
     __shared__ int sh_pos, sh_got, sh_stop;
-    const int e = blockIdx.x;
     const int t = threadIdx.x;
     uint32_t* gs = mt_state + (size_t)e * kMtN;
     for (int i = t; i < kMtN; i += 256) s[i] = gs[i];
@@ -168,6 +154,34 @@ __global__ void __launch_bounds__(256) k_mt_normal(uint32_t* __restrict__ mt_sta
 }
 
 template <typename T>
+__global__ void __launch_bounds__(256) k_mt_normal(uint32_t* __restrict__ mt_state, int* __restrict__ mt_pos,
+                                                   T* __restrict__ zx, int K, int n_inner, int n_outer) {
+    mt_normal_body<T>(mt_state, mt_pos, zx, K, n_inner, n_outer, blockIdx.x);
+}
+
+// One launch for the two independent halves of the ring operand [Z | xi] of env blockIdx.y:
+// blockIdx.x == 0 gathers Z, blockIdx.x == 1 draws the n_outer innovations xi of the layer's MT19937 stream.
+template <typename T>
+__global__ void __launch_bounds__(256) k_ring_prepare(const T* __restrict__ map, T* __restrict__ zx,
+                                                      const int* __restrict__ inner_idx, uint32_t* __restrict__ mt_state,
+                                                      int* __restrict__ mt_pos, int S, int n_inner, int n_outer, int K,
+                                                      int sx, int sy, int oy, int ox) {
+    const int e = blockIdx.y;
+    if (blockIdx.x == 0) gather_ring<T>(map, zx, inner_idx, S, n_inner, K, sx, sy, oy, ox, e, threadIdx.x, 256);
+    else mt_normal_body<T>(mt_state, mt_pos, zx, K, n_inner, n_outer, e);
+}
+
+template <typename T>
+int launch_ring_prepare(const T* map, T* zx, const int* inner_idx, uint32_t* mt_state, int* mt_pos, int n_env, int S,
+                        int n_inner, int n_outer, int K, int sx, int sy, int oy, int ox, hipStream_t st) {
+    if (n_outer % 2) return fail("mt_normal: n_outer=%d must be even", n_outer);
+    hipLaunchKernelGGL(k_ring_prepare<T>, dim3(2, n_env), dim3(256), 0, st, map, zx, inner_idx, mt_state, mt_pos, S, n_inner,
+                       n_outer, K, sx, sy, oy, ox);
+    AO_HIP(hipGetLastError());
+    return 0;
+}
+
+template <typename T>
 int launch_mt_normal(uint32_t* mt_state, int* mt_pos, T* zx, int n_env, int K, int n_inner, int n_outer,
                      hipStream_t st) {
     if (n_outer % 2) return fail("mt_normal: n_outer=%d must be even", n_outer);
@@ -177,28 +191,16 @@ int launch_mt_normal(uint32_t* mt_state, int* mt_pos, T* zx, int n_env, int K, i
 }
 
 // ---------------------------------------------------------------------------------------------------
-// add_row, part 3: map_full[outerMask] = X   (+ min / max of the whole new map, which the sub-pixel
-// warp clips its output to: skimage clip=True).  One workgroup per env.
+// add_row, part 3: map_full[outerMask] = X through the NEW origin (+ min / max of the whole new map, which the
+// sub-pixel warp clips its output to: skimage clip=True; with_minmax = 0 leaves that to the consumer -- the fused
+// step kernel recomputes it from the map it reads anyway).  One workgroup per env.
 // ---------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void __launch_bounds__(1024) k_scatter_minmax(T* __restrict__ new_map, const T* __restrict__ X,
-                                                         const int* __restrict__ outer_idx, T* __restrict__ minmax,
-                                                         int S, int n_outer, int splits, size_t slab) {
+__device__ inline void block_minmax(const T* __restrict__ map, T* __restrict__ minmax, int S, int e) {
     __shared__ T red_lo[16], red_hi[16];
-    const int e = blockIdx.x;
-    T* map = new_map + (size_t)e * S * S;
-    const T* x = X + (size_t)e * n_outer;
     T lo = (T)3.0e38, hi = (T)-3.0e38;
-    for (int k = threadIdx.x; k < n_outer; k += blockDim.x) {
-        T v = x[k];
-        for (int z = 1; z < splits; ++z) v += x[(size_t)z * slab + k];       // split-K slabs, fixed order
-        map[outer_idx[k]] = v;
-        lo = v < lo ? v : lo;
-        hi = v > hi ? v : hi;
-    }
-    const int N = S - 2;
-    for (int i = threadIdx.x; i < N * N; i += blockDim.x) {
-        const T v = map[(i / N + 1) * S + (i % N) + 1];
+    for (int i = threadIdx.x; i < S * S; i += blockDim.x) {        // the torus is a permutation: scan physically
+        const T v = map[i];
         lo = v < lo ? v : lo;
         hi = v > hi ? v : hi;
     }
@@ -224,19 +226,53 @@ __global__ void __launch_bounds__(1024) k_scatter_minmax(T* __restrict__ new_map
 }
 
 template <typename T>
+__global__ void __launch_bounds__(1024) k_scatter_minmax(T* __restrict__ new_map, const T* __restrict__ X,
+                                                         const int* __restrict__ outer_idx, T* __restrict__ minmax,
+                                                         int S, int n_outer, int splits, size_t slab, int oy, int ox,
+                                                         int with_minmax) {
+    const int e = blockIdx.x;
+    T* map = new_map + (size_t)e * S * S;
+    const T* x = X + (size_t)e * n_outer;
+    for (int k = threadIdx.x; k < n_outer; k += blockDim.x) {
+        T v = x[k];
+        for (int z = 1; z < splits; ++z) v += x[(size_t)z * slab + k];       // split-K slabs, fixed order
+        const int idx = outer_idx[k];
+        map[torus(idx / S, idx % S, oy, ox, S)] = v;
+    }
+    if (!with_minmax) return;
+    __syncthreads();                                               // the ring is in place (this workgroup wrote it)
+    block_minmax<T>(map, minmax, S, e);
+}
+
+template <typename T>
 int launch_scatter_minmax(T* new_map, const T* X, const int* outer_idx, T* minmax, int n_env, int S, int n_outer,
-                          int splits, hipStream_t st) {
-    hipLaunchKernelGGL(k_scatter_minmax<T>, dim3(n_env), dim3(1024), 0, st, new_map, X, outer_idx, minmax, S,
-                       n_outer, splits, (size_t)n_env * n_outer);
+                          int splits, int oy, int ox, int with_minmax, hipStream_t st) {
+    hipLaunchKernelGGL(k_scatter_minmax<T>, dim3(n_env), dim3(with_minmax ? 1024 : 512), 0, st, new_map, X, outer_idx, minmax, S,
+                       n_outer, splits, (size_t)n_env * n_outer, oy, ox, with_minmax);
+    AO_HIP(hipGetLastError());
+    return 0;
+}
+
+// min / max of every env's map on its own (a consumer other than the fused step kernel needs it after a lean scatter)
+template <typename T>
+__global__ void __launch_bounds__(1024) k_minmax(const T* __restrict__ maps, T* __restrict__ minmax, int S) {
+    block_minmax<T>(maps + (size_t)blockIdx.x * S * S, minmax, S, blockIdx.x);
+}
+
+template <typename T>
+int launch_minmax(const T* maps, T* minmax, int n_env, int S, hipStream_t st) {
+    hipLaunchKernelGGL(k_minmax<T>, dim3(n_env), dim3(1024), 0, st, maps, minmax, S);
     AO_HIP(hipGetLastError());
     return 0;
 }
 
 #define INST(T)                                                                                                    \
-    template int launch_shift_gather<T>(const T*, T*, T*, const int*, int, int, int, int, int, int, int,           \
-                                        hipStream_t);                                                              \
+    template int launch_ring_prepare<T>(const T*, T*, const int*, uint32_t*, int*, int, int, int, int, int, int, int, \
+                                        int, int, hipStream_t);                                                    \
     template int launch_mt_normal<T>(uint32_t*, int*, T*, int, int, int, int, hipStream_t);                        \
-    template int launch_scatter_minmax<T>(T*, const T*, const int*, T*, int, int, int, int, hipStream_t);
+    template int launch_scatter_minmax<T>(T*, const T*, const int*, T*, int, int, int, int, int, int, int,         \
+                                          hipStream_t);                                                            \
+    template int launch_minmax<T>(const T*, T*, int, int, hipStream_t);
 INST(float)
 INST(double)
 #undef INST

@@ -38,6 +38,7 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // and the 4 Catmull-Rom tap weights are the same for every pixel, so they are computed once on the host
 // in float64 from the float64 accumulator (as the reference's float64 warp sees it).
 struct LayerTaps {
+    int oy, ox;            // origin of the torus the screen is stored as: logical (r, c) at ((r + oy) % S, (c + ox) % S)
     int dy, dx;            // floor(-buff_y), floor(-buff_x)  in {-1, 0}
     double wy[4], wx[4];   // Catmull-Rom weights of the taps at floor-1 .. floor+2
     double weight;         // sqrt(fractionalR0)
@@ -53,6 +54,7 @@ struct PhaseArgs {
     int update_atm;                  // 1: atmosphere OPD from the screens; 0: from the opd_atm buffer (user-defined OPD)
     int store_atm;                   // 1: also write atm.OPD_no_pupil to the opd_atm buffer (state inspection)
     int store_phase;                 // 0: leave the residual phase, the telemetry sums and wfs_max untouched
+    int minmax_dirty[kMaxLayer];     // fused step kernel: 1 = recompute the layer's min / max from the map and store it
 };
 
 }  // namespace ao
@@ -63,14 +65,16 @@ namespace ao {
 struct Env;  // host object, env.hpp
 
 template <typename T>
-int launch_shift_gather(const T* old_map, T* new_map, T* zx, const int* inner_idx, int n_env, int S, int n_inner,
-                        int K, int sx, int sy, int do_copy, hipStream_t st);
+int launch_ring_prepare(const T* map, T* zx, const int* inner_idx, uint32_t* mt_state, int* mt_pos, int n_env, int S,
+                        int n_inner, int n_outer, int K, int sx, int sy, int oy, int ox, hipStream_t st);
 template <typename T>
 int launch_mt_normal(uint32_t* mt_state, int* mt_pos, T* zx, int n_env, int K, int n_inner, int n_outer,
                      hipStream_t st);
 template <typename T>
 int launch_scatter_minmax(T* new_map, const T* X, const int* outer_idx, T* minmax, int n_env, int S, int n_outer,
-                          int splits, hipStream_t st);
+                          int splits, int oy, int ox, int with_minmax, hipStream_t st);
+template <typename T>
+int launch_minmax(const T* maps, T* minmax, int n_env, int S, hipStream_t st);
 int gemm_splits(int M, int N, int K);
 int launch_gemm_nt_mfma(const float* X, const float* W, float* Cpart, int M, int N, int K, int ldx, int ldw, int splits,
                         hipStream_t st);

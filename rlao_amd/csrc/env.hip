@@ -38,11 +38,13 @@ struct AoEnv {
     int R = 0, N = 0, S = 0, A = 0, nAct = 0, E = 0, L = 0, nin = 0, nout = 0, K = 0, nSig = 0, nSub = 0, nVal = 0;
     int p = 0, n = 0, n_pupil = 0;
     LayerClock clk[kMaxLayer];
-    int cur[kMaxLayer] = {0};
+    int cur[kMaxLayer] = {0};                // (always 0: the screens are tori, nothing is copied on a shift)
+    int org[kMaxLayer][2] = {{0, 0}};        // torus origin (oy, ox) of every layer: logical (r, c) at ((r + oy) % S, (c + ox) % S)
+    bool minmax_dirty[kMaxLayer] = {false};  // the layer's min / max table is stale (ring extruded without the min / max pass)
     bool have[AOENV_C_COUNT] = {false};
     double units = 1.0;
     // device memory (element type = dtype unless noted)
-    void* screen[2] = {nullptr, nullptr};   // [L][E][S*S] ping-pong
+    void* screen[2] = {nullptr, nullptr};   // [0]: [L][E][S*S] tori ([1] unused)
     void* minmax = nullptr;                 // [L][E][2]
     uint32_t* mt_state = nullptr;           // [L][E][624]
     int* mt_pos = nullptr;                  // [L][E]
@@ -208,21 +210,18 @@ int gemm_dispatch<double>(AoEnv*, const double* X, const double* W, double* C, i
 }
 
 // ---- add_row on the device (OOPAO/Atmosphere.py:301-311) for every env of the shard ---------------
+// lean = true: the ring is scattered without the min / max pass; the fused step kernel recomputes the range from the map
 template <typename T>
-int extrude(AoEnv* env, int l, int sx, int sy, bool copy, hipStream_t st) {
-    const int from = env->cur[l], to = copy ? 1 - from : from;
-    T* oldm = env->as<T>(env->screen_ptr(from, l));
-    T* newm = env->as<T>(env->screen_ptr(to, l));
+int extrude(AoEnv* env, int l, int sx, int sy, bool lean, hipStream_t st) {
+    T* map = env->as<T>(env->screen_ptr(0, l));
     T* zx = env->as<T>(env->zx);
+    const int S = env->S;
+    const int oy = env->org[l][0], ox = env->org[l][1];
     {
-        AO_PROF(env, SHIFT_GATHER, st);
-        AO_TRY(launch_shift_gather<T>(oldm, newm, zx, env->inner_idx, env->E, env->S, env->nin, env->K, sx, sy,
-                                      copy ? 1 : 0, st));
-    }
-    {
-        AO_PROF(env, MT_NORMAL, st);
-        AO_TRY(launch_mt_normal<T>(env->mt_state + (size_t)l * env->E * kMtN, env->mt_pos + (size_t)l * env->E, zx,
-                                   env->E, env->K, env->nin, env->nout, st));
+        AO_PROF(env, SHIFT_GATHER, st);                           // Z gather + xi draw, one launch
+        AO_TRY(launch_ring_prepare<T>(map, zx, env->inner_idx, env->mt_state + (size_t)l * env->E * kMtN,
+                                      env->mt_pos + (size_t)l * env->E, env->E, S, env->nin, env->nout, env->K, sx, sy, oy, ox,
+                                      st));
     }
     int splits = 1;
     {
@@ -230,32 +229,46 @@ int extrude(AoEnv* env, int l, int sx, int sy, bool copy, hipStream_t st) {
         AO_TRY(gemm_dispatch<T>(env, zx, env->as<T>(env->ab), env->as<T>(env->xbuf), env->E, env->nout, env->K, &splits,
                                 st));
     }
+    // the shift itself: move the origin of the torus
+    env->org[l][0] = ((oy - sy) % S + S) % S;
+    env->org[l][1] = ((ox - sx) % S + S) % S;
     {
         AO_PROF(env, SCATTER, st);
-        AO_TRY(launch_scatter_minmax<T>(newm, env->as<T>(env->xbuf), env->outer_idx, env->as<T>(env->minmax_ptr(l)),
-                                        env->E, env->S, env->nout, splits, st));
+        AO_TRY(launch_scatter_minmax<T>(map, env->as<T>(env->xbuf), env->outer_idx, env->as<T>(env->minmax_ptr(l)), env->E, S,
+                                        env->nout, splits, env->org[l][0], env->org[l][1], lean ? 0 : 1, st));
     }
-    env->cur[l] = to;
+    env->minmax_dirty[l] = lean;
+    return 0;
+}
+
+// make every layer's min / max table current (consumers other than the fused step kernel)
+template <typename T>
+int refresh_minmax(AoEnv* env, hipStream_t st) {
+    for (int l = 0; l < env->L; ++l)
+        if (env->minmax_dirty[l]) {
+            AO_TRY(launch_minmax<T>(env->as<T>(env->screen_ptr(0, l)), env->as<T>(env->minmax_ptr(l)), env->E, env->S, st));
+            env->minmax_dirty[l] = false;
+        }
     return 0;
 }
 
 // ---- atm.update(): host clock of updateLayer (OOPAO/Atmosphere.py:350-407) -----------------------
 template <typename T>
-int advance_atmosphere(AoEnv* env, hipStream_t st) {
+int advance_atmosphere(AoEnv* env, bool lean, hipStream_t st) {
     for (int l = 0; l < env->L; ++l) {
         LayerClock& k = env->clk[l];
         if (k.ratio[0] == 0 && k.ratio[1] == 0) continue;
         const int ns[2] = {(int)std::fabs(k.ratio[0]), (int)std::fabs(k.ratio[1])};
         const int mn = ns[0] < ns[1] ? ns[0] : ns[1], mx = ns[0] > ns[1] ? ns[0] : ns[1];
         const int s0 = (int)sgn(k.ratio[0]), s1 = (int)sgn(k.ratio[1]);
-        for (int i = 0; i < mn; ++i) AO_TRY(extrude<T>(env, l, s0, s1, true, st));
+        for (int i = 0; i < mn; ++i) AO_TRY(extrude<T>(env, l, s0, s1, lean, st));
         for (int j = 0; j < mx - mn; ++j)
-            AO_TRY(extrude<T>(env, l, ns[0] == mn ? 0 : s0, ns[1] == mn ? 0 : s1, true, st));
+            AO_TRY(extrude<T>(env, l, ns[0] == mn ? 0 : s0, ns[1] == mn ? 0 : s1, lean, st));
         for (int d = 0; d < 2; ++d) k.buff[d] += std::fmod(std::fabs(k.ratio[d]), 1.0) * sgn(k.ratio[d]);
         if (std::fabs(k.buff[0]) >= 1 || std::fabs(k.buff[1]) >= 1) {
             const int b0 = std::fabs(k.buff[0]) < 1 ? 0 : (int)sgn(k.buff[0]);
             const int b1 = std::fabs(k.buff[1]) < 1 ? 0 : (int)sgn(k.buff[1]);
-            AO_TRY(extrude<T>(env, l, b0, b1, true, st));
+            AO_TRY(extrude<T>(env, l, b0, b1, lean, st));
         }
         for (int d = 0; d < 2; ++d) k.buff[d] = std::fmod(std::fabs(k.buff[d]), 1.0) * sgn(k.buff[d]);
     }
@@ -267,6 +280,7 @@ void fill_phase_args(AoEnv* env, PhaseArgs& pa, PhaseBuffers<T>& pb, int update_
 
 template <typename T>
 int run_phase(AoEnv* env, int update_atm, int store_atm, hipStream_t st, int store_phase = 1) {
+    AO_TRY(refresh_minmax<T>(env, st));
     PhaseArgs pa;
     PhaseBuffers<T> pb;
     fill_phase_args<T>(env, pa, pb, update_atm, store_atm, store_phase);
@@ -399,9 +413,12 @@ void fill_phase_args(AoEnv* env, PhaseArgs& pa, PhaseBuffers<T>& pb, int update_
     pa.store_atm = store_atm;
     pa.store_phase = store_phase;
     for (int l = 0; l < env->L; ++l) {
-        pa.screen[l] = env->screen_ptr(env->cur[l], l);
+        pa.screen[l] = env->screen_ptr(0, l);
         pa.minmax[l] = env->minmax_ptr(l);
+        pa.minmax_dirty[l] = env->minmax_dirty[l] ? 1 : 0;
         LayerTaps& t = pa.taps[l];
+        t.oy = env->org[l][0];
+        t.ox = env->org[l][1];
         const double fy = -env->clk[l].buff[1], fx = -env->clk[l].buff[0];
         const double ky = std::floor(fy), kx = std::floor(fx);
         t.dy = (int)ky;
@@ -460,16 +477,21 @@ int run_fused_step<float>(AoEnv* env, int i, const void* d_action, void* d_obs, 
     a.n_subap = env->nSub;
     a.n_valid = env->nVal;
     a.n_env = env->E;
-    AO_PROF(env, ENV_STEP, st);
-    return launch_env_step(a, st);
+    {
+        AO_PROF(env, ENV_STEP, st);
+        AO_TRY(launch_env_step(a, st));
+    }
+    for (int l = 0; l < env->L; ++l) env->minmax_dirty[l] = false;   // the kernel recomputed and stored them
+    return 0;
 }
 
 template <typename T>
 int step_t(AoEnv* env, int i, const void* d_action, void* d_obs, void* d_frame, void* d_reward, void* d_strehl,
            double gain, hipStream_t st) {
-    AO_TRY(advance_atmosphere<T>(env, st));
+    const bool fused_step = fused_step_ok<T>(env);
+    AO_TRY(advance_atmosphere<T>(env, fused_step, st));
     env->atm_user_defined = false;
-    if (fused_step_ok<T>(env)) {
+    if (fused_step) {
         AO_TRY(run_fused_step<T>(env, i, d_action, d_obs, d_reward, d_strehl, gain, st));
         if (d_frame)
             AO_HIP(hipMemcpyAsync(d_frame, env->frame, (size_t)env->E * env->c.cam_res * env->c.cam_res * sizeof(T),
@@ -595,7 +617,6 @@ int aoenv_create(const AoCfg* cfg, int device, AoEnv** out) {
     auto A_ = [&](void** p, size_t bytes) { if (!rc) rc = dmalloc(e, p, bytes); };
     if (e->L > 0) {
         A_(&e->screen[0], (size_t)e->L * E * e->S * e->S * z);
-        A_(&e->screen[1], (size_t)e->L * E * e->S * e->S * z);
         A_(&e->minmax, (size_t)e->L * E * 2 * z);
         A_((void**)&e->mt_state, (size_t)e->L * E * kMtN * 4);
         A_((void**)&e->mt_pos, (size_t)e->L * E * 4);
@@ -866,7 +887,7 @@ static int finish_new_screens(AoEnv* env, const uint32_t* h_ring_seeds, hipStrea
     AO_HIP(hipMemcpy(env->mt_pos, pos.data(), pos.size() * 4, hipMemcpyHostToDevice));
     for (int l = 0; l < L; ++l) {
         env->clk[l].buff[0] = env->clk[l].buff[1] = 0;            // notDoneOnce (OOPAO/Atmosphere.py:586, 359-364)
-        AO_TRY(AO_DISPATCH(env, extrude, env, l, 0, 0, false, st));
+        AO_TRY(AO_DISPATCH(env, extrude, env, l, 0, 0, false, st));   // (the callers reset the torus origin with the new interior)
     }
     env->atm_user_defined = false;
     AO_TRY(AO_DISPATCH(env, run_phase, env, 1, 1, st));            // fill_phase_support + set_OPD + atm*tel
@@ -881,6 +902,10 @@ int aoenv_new_screens(AoEnv* env, const double* h_screens, const uint32_t* h_rin
     hipStream_t st = static_cast<hipStream_t>(stream);
     AO_HIP(hipStreamSynchronize(st));
     const int E = env->E, L = env->L, N = env->N, S = env->S;
+    if (!h_screens)
+        for (int l = 0; l < L; ++l)
+            if (env->org[l][0] || env->org[l][1]) return fail("keeping the interior is only possible before the first shift");
+    for (int l = 0; l < L; ++l) env->org[l][0] = env->org[l][1] = 0;
     if (h_screens) {
         // mapShift[~outerMask] = phase  (OOPAO/Atmosphere.py:585); the ring is drawn below
         std::vector<char> host((size_t)E * S * S * env->esz);
@@ -895,7 +920,7 @@ int aoenv_new_screens(AoEnv* env, const double* h_screens, const uint32_t* h_rin
                         else reinterpret_cast<double*>(host.data())[o] = src[(size_t)r * N + c];
                     }
             }
-            AO_HIP(hipMemcpy(env->screen_ptr(env->cur[l], l), host.data(), host.size(), hipMemcpyHostToDevice));
+            AO_HIP(hipMemcpy(env->screen_ptr(0, l), host.data(), host.size(), hipMemcpyHostToDevice));
         }
     }
     return finish_new_screens(env, h_ring_seeds, st);
@@ -930,6 +955,7 @@ int aoenv_new_screens_device(AoEnv* env, const uint32_t* h_screen_seeds, const u
     AO_HIP(hipStreamSynchronize(st));
     const int E = env->E, L = env->L, N = env->N, S = env->S;
     if (N % 2) return fail("the screen generator needs an even layer size, got %d", N);
+    for (int l = 0; l < L; ++l) env->org[l][0] = env->org[l][1] = 0;
     const size_t N2 = (size_t)N * N;
 
     // frequency-grid amplitude sqrt(PSD) del_f (phaseStats.py:209-222) and the 3 x 4 sub-harmonic terms (:277-309)
@@ -991,7 +1017,7 @@ int aoenv_new_screens_device(AoEnv* env, const uint32_t* h_screen_seeds, const u
             AO_HIP(hipMemcpyAsync(d_pos, pos.data(), (size_t)ne * 4, hipMemcpyHostToDevice, st));
             AO_TRY(launch_mt_normal<double>(d_mt, d_pos, d_nrm, ne, (int)(2 * N2), 0, (int)(2 * N2), st));
             sa.n_env = ne;
-            char* map = static_cast<char*>(env->screen_ptr(env->cur[l], l)) + (size_t)e0 * S * S * env->esz;
+            char* map = static_cast<char*>(env->screen_ptr(0, l)) + (size_t)e0 * S * S * env->esz;
             if (env->esz == 4) AO_TRY(launch_screen<float>(sa, reinterpret_cast<float*>(map), S, st));
             else AO_TRY(launch_screen<double>(sa, reinterpret_cast<double*>(map), S, st));
             AO_HIP(hipStreamSynchronize(st));                      // keys / pos are reused by the next chunk
@@ -1087,9 +1113,22 @@ int aoenv_download(AoEnv* env, int which, void* h_dst, size_t bytes, void* strea
     hipStream_t st = static_cast<hipStream_t>(stream);
     AO_HIP(hipStreamSynchronize(st));
     if (which == AOENV_B_SCREEN) {
-        const size_t per = (size_t)env->E * env->S * env->S * env->esz;
-        for (int l = 0; l < env->L; ++l)
-            AO_HIP(hipMemcpy(static_cast<char*>(h_dst) + l * per, env->screen_ptr(env->cur[l], l), per, hipMemcpyDeviceToHost));
+        // the device keeps every screen as a torus: hand back the logical layer.mapShift
+        const int S = env->S;
+        const size_t per = (size_t)env->E * S * S * env->esz, z = env->esz;
+        std::vector<char> tmp(per);
+        for (int l = 0; l < env->L; ++l) {
+            AO_HIP(hipMemcpy(tmp.data(), env->screen_ptr(0, l), per, hipMemcpyDeviceToHost));
+            char* dst = static_cast<char*>(h_dst) + l * per;
+            const int oy = env->org[l][0], ox = env->org[l][1];
+            for (int e = 0; e < env->E; ++e)
+                for (int r = 0; r < S; ++r) {
+                    const char* srow = tmp.data() + ((size_t)e * S * S + (size_t)((r + oy) % S) * S) * z;
+                    char* drow = dst + ((size_t)e * S * S + (size_t)r * S) * z;
+                    std::memcpy(drow, srow + (size_t)ox * z, (size_t)(S - ox) * z);
+                    std::memcpy(drow + (size_t)(S - ox) * z, srow, (size_t)ox * z);
+                }
+        }
         return 0;
     }
     if (which == AOENV_B_OPD_ATM && env->L > 0 && !env->atm_user_defined && !env->store_opd_atm) {

@@ -89,7 +89,10 @@ __global__ void __launch_bounds__(256) k_phase(const KArgs<T> a) {
                 const int rr = r0 + r;
                 for (int c = lx; c < txe + 3; c += 64) {
                     const int cc = c0 + c;
-                    mapt[r * MW + c] = (rr >= 0 && rr < S && cc >= 0 && cc < S) ? map[(size_t)rr * S + cc] : (T)0;
+                    int pr = rr + tp.oy, pc = cc + tp.ox;           // torus: physical = (logical + origin) mod S
+                    pr = pr >= S ? pr - S : pr;
+                    pc = pc >= S ? pc - S : pc;
+                    mapt[r * MW + c] = (rr >= 0 && rr < S && cc >= 0 && cc < S) ? map[(size_t)pr * S + pc] : (T)0;
                 }
             }
             __syncthreads();
@@ -265,8 +268,11 @@ __global__ void __launch_bounds__(256) k_phase_mfma(const KArgs<float> a) {
                     const int idx = tid + 256 * k;
                     const int r = idx / MW, c = idx - r * MW;
                     const int rr = r0 + r, cc = c0 + c;
+                    int pr = rr + tp.oy, pc = cc + tp.ox;           // torus: physical = (logical + origin) mod S
+                    pr = pr >= S ? pr - S : pr;
+                    pc = pc >= S ? pc - S : pc;
                     v[k] = (idx < (kTY + 3) * MW && r < tye + 3 && c < txe + 3 && rr >= 0 && rr < S && cc >= 0 && cc < S)
-                               ? map[(size_t)rr * S + cc] : 0.f;
+                               ? map[(size_t)pr * S + pc] : 0.f;
                 }
 #pragma unroll
                 for (int k = 0; k < NV; ++k) {

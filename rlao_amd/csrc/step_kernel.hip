@@ -162,6 +162,43 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
         }
     }
 
+    // ---- range of every layer's screen (the warp clips to it): read back, or recomputed here after a ring extrusion -------
+    __shared__ float lohi[kMaxLayer][2];
+    __shared__ float red_lo[16], red_hi[16];
+    for (int l = 0; l < k.pa.n_layer; ++l) {
+        float* mm = const_cast<float*>(static_cast<const float*>(k.pa.minmax[l])) + 2 * e;
+        if (!k.pa.minmax_dirty[l]) {
+            if (tid < 2) lohi[l][tid] = mm[tid];
+            continue;
+        }
+        // the torus is a permutation of the (N+2)^2 pixels: scan it physically with 16-byte loads
+        const float* map = static_cast<const float*>(k.pa.screen[l]) + (size_t)e * S * S;
+        const int n4 = (S * S) / 4;                              // env maps are 16-byte aligned when S*S % 4 == 0
+        float lo = 3.0e38f, hi = -3.0e38f;
+        if ((S * S) % 4 == 0) {
+            for (int i = tid; i < n4; i += 1024) {
+                const f32x4s v = *reinterpret_cast<const f32x4s*>(map + 4 * i);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) { lo = v[d] < lo ? v[d] : lo; hi = v[d] > hi ? v[d] : hi; }
+            }
+        } else {
+            for (int i = tid; i < S * S; i += 1024) { const float v = map[i]; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ol = __shfl_down(lo, off), oh = __shfl_down(hi, off);
+            lo = ol < lo ? ol : lo;
+            hi = oh > hi ? oh : hi;
+        }
+        lds_barrier();                                           // red_lo / red_hi of the previous layer consumed
+        if (lane == 0) { red_lo[w] = lo; red_hi[w] = hi; }
+        lds_barrier();
+        if (tid == 0) {
+            for (int i = 1; i < 16; ++i) { lo = red_lo[i] < lo ? red_lo[i] : lo; hi = red_hi[i] > hi ? red_hi[i] : hi; }
+            lohi[l][0] = lo; lohi[l][1] = hi;
+            mm[0] = lo; mm[1] = hi;
+        }
+    }
+
     // Lane -> pixel map of a pass (64 rows): wave = (band = w >> 2: 16 rows, cg = w & 3: 32 columns = 2 tiles of 16);
     // in a tile the lane owns ONE row y = 16 band + (lane & 15) and FOUR CONSECUTIVE columns x = 16 tile + 4 (lane >> 4) + r.
     // That is the output layout of the matrix cores for D[x][y] = sum_k Gx^T[k][x] s1[y][k] (rows 4 (lane >> 4) + r = x,
@@ -203,15 +240,23 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
                     const int idx = tid + 1024 * q;
                     const int r = idx / MW4, c = 4 * (idx - r * MW4);
                     const int rr = r0 + r, cc = c0 + c;
-                    const bool ok = idx < (PR + 3) * MW4 && r < tye + 3 && c < R + 3 && rr >= 0 && rr < S && cc >= 0 && cc + 3 < S;
-                    const float* src = map + (ok ? (size_t)rr * S + cc : 0);
+                    const bool need = idx < (PR + 3) * MW4 && r < tye + 3 && c < R + 3 && rr >= 0 && rr < S && cc >= 0 && cc < S;
+                    int pr = rr + tp.oy, pc = cc + tp.ox;         // torus: physical = (logical + origin) mod S
+                    pr = pr >= S ? pr - S : pr;
+                    pc = pc >= S ? pc - S : pc;
+                    const bool ok = need && cc + 3 < S && pc + 3 < S;      // the 4 columns are contiguous in memory
+                    const float* src = map + (ok ? (size_t)pr * S + pc : 0);
                     f32x4s t;                                     // the screen rows are only 4-byte aligned (S = R + 6)
                     __builtin_memcpy(&t, src, 16);
                     v[q] = ok ? t : f32x4s{0.f, 0.f, 0.f, 0.f};
-                    if (!ok && idx < (PR + 3) * MW4 && r < tye + 3 && c < R + 3 && rr >= 0 && rr < S) {
-                        // a float4 that straddles the right edge of the screen: element by element (never at S = R + 6)
-                        for (int d = 0; d < 4; ++d)
-                            if (cc + d >= 0 && cc + d < S) v[q][d] = map[(size_t)rr * S + cc + d];
+                    if (need && !ok) {
+                        // a float4 that straddles the wrap of the torus or the edge of the screen: element by element
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) {
+                            int pd = pc + d;
+                            pd = pd >= S ? pd - S : pd;
+                            if (cc + d < S) v[q][d] = map[(size_t)pr * S + pd];
+                        }
                     }
                 }
 #pragma unroll
@@ -224,8 +269,7 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
             AO_STAMP(4 + 6 * pass);
             const float wx0 = (float)tp.wx[0], wx1 = (float)tp.wx[1], wx2 = (float)tp.wx[2], wx3 = (float)tp.wx[3];
             const float wy0 = (float)tp.wy[0], wy1 = (float)tp.wy[1], wy2 = (float)tp.wy[2], wy3 = (float)tp.wy[3];
-            const float* mm = static_cast<const float*>(k.pa.minmax[l]) + 2 * e;
-            const float lo = mm[0], hi = mm[1], wl = (float)tp.weight;
+            const float lo = lohi[l][0], hi = lohi[l][1], wl = (float)tp.weight;
             const bool zero_outside = (lo > 0.f || hi < 0.f);
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
