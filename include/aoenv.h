@@ -182,6 +182,26 @@ int aoenv_step(AoEnv* env, int i, const void* d_action, void* d_obs, void* d_fra
 int aoenv_run_integrator(AoEnv* env, int i0, int n_steps, double gain, void* d_obs, void* d_frame,
                          void* d_reward, void* d_strehl, void* stream);
 
+/* Replaces: the WFS camera settings wfs.cam.{photonNoise, readoutNoise, QE, darkCurrent, integrationTime, FWC, bits, gain,
+ * sensor} (OOPAO/Detector.py:19-60; Papyrus: photonNoise = True, MAIN/OOPAOEnv/OOPAOEnv.py:379; Razor:
+ * OOPAOEnvRazor.py:243-250, 333).  The frame of every measurement then goes through integrate() + readout()
+ * (Detector.py:232-301) before the slopes are computed.  The reference seeds its noise generators from the wall clock;
+ * here every pixel of every frame draws from a counter-based stream keyed by `seed` and indexed by (pixel, env_index_offset
+ * + env, frame number): reproducible, and the same for an env wherever it sits in a batch.  NULL = ideal detector. */
+typedef struct AoDetector {
+    int32_t photon_noise;    /* cam.photonNoise */
+    int32_t bits;            /* ADC bits, 0 = None (needs fwc > 0 when set) */
+    int32_t emccd;           /* sensor == 'EMCCD': gain before the read-out noise; CCD / CMOS: after */
+    int32_t env_index_offset; /* global index of env 0 of this shard (multi-GPU sharding) */
+    double  qe;              /* cam.QE */
+    double  dark_electrons;  /* cam.darkCurrent * cam.integrationTime */
+    double  fwc;             /* cam.FWC, 0 = None */
+    double  gain;            /* cam.gain */
+    double  readout_noise;   /* cam.readoutNoise [e- rms] */
+    uint64_t seed;
+} AoDetector;
+int aoenv_set_detector(AoEnv* env, const AoDetector* cfg);
+
 /* Episode return on the device (the sum of rewards the trainers accumulate on the host, MAIN/PO4AO/mbrl.py:64-89):
  * d_return [n_env] is a caller-owned device buffer of the env dtype; every aoenv_step / integrator step adds its reward
  * to it.  NULL detaches it.  The caller zeroes it at the start of an episode. */

@@ -606,6 +606,51 @@ class OraclePyramid:
         return maps, maps[np.where(self.validSignal == 1)]
 
 
+
+# --------------------------------------------------------------------------------------
+# Detector                                                   (OOPAO/Detector.py:178-301)
+# --------------------------------------------------------------------------------------
+class Detector:
+    """WFS camera: photon noise, quantum efficiency, dark shot noise, saturation, read-out noise, ADC.
+
+    ``integrate`` + ``readout`` of the reference for one frame per read-out (integrationTime equal to the loop's
+    samplingTime or None), binning 1, no background map.  The reference seeds its four RandomStates from the wall
+    clock (Detector.py:127-130), so a noisy frame is reproducible only in distribution; here the seed is explicit.
+    With every noise source off the path is deterministic (QE, saturation clip, ADC truncation) and bit-comparable."""
+
+    def __init__(self, photonNoise=False, readoutNoise=0.0, QE=1.0, darkCurrent=0.0, integrationTime=None, FWC=None,
+                 bits=None, gain=1, sensor="CCD", seed=0):
+        if sensor not in ("EMCCD", "CCD", "CMOS"):
+            raise ValueError("Sensor must be 'EMCCD', 'CCD', or 'CMOS'")                   # :40-41
+        self.photonNoise, self.readoutNoise, self.QE = photonNoise, readoutNoise, QE
+        self.darkCurrent, self.integrationTime, self.FWC = darkCurrent, integrationTime, FWC
+        self.bits, self.gain, self.sensor = bits, gain, sensor
+        self.rs_photon, self.rs_readout, self.rs_dark = RandomState(seed), RandomState(seed + 1), RandomState(seed + 2)
+
+    def integrate(self, frame: np.ndarray) -> np.ndarray:
+        frame = np.array(frame, dtype=np.float64)
+        if self.photonNoise:                                                               # :204-206, :285-286
+            frame = self.rs_photon.poisson(frame).astype(np.float64)
+        frame = frame * self.QE                                                            # :178-180
+        if self.darkCurrent != 0:                                                          # :224-229, :235-236
+            frame = frame + self.rs_dark.poisson(np.ones(frame.shape) * (self.darkCurrent * self.integrationTime))
+        if self.FWC is not None:                                                           # :183-187
+            frame = np.clip(frame, 0, self.FWC)
+        if self.sensor == "EMCCD":                                                         # :243-244
+            frame = frame * self.gain
+        if self.readoutNoise != 0:                                                         # :218-221
+            frame = frame + np.round(self.rs_readout.randn(*frame.shape) * self.readoutNoise).astype(int)
+        if self.sensor in ("CCD", "CMOS"):                                                 # :258-259
+            frame = frame * self.gain
+        if self.bits is not None:                                                          # :190-201
+            if self.FWC is None:
+                frame = (frame / frame.max() * 2 ** self.bits).astype(np.int64)
+            else:
+                frame = (frame / self.FWC * (2 ** self.bits - 1)).astype(np.int64)          # truncation toward zero
+                frame = np.clip(frame, frame.min(), 2 ** self.bits - 1)
+            frame = frame.astype(np.float64)
+        return frame
+
 # --------------------------------------------------------------------------------------
 # Zernike basis (Noll), as the reference builds it          (OOPAO/Zernike.py:26-66)
 # aotools 1.0.6 (third party, absent) supplies zernIndex / zernikeRadialFunc: restated here.

@@ -210,6 +210,42 @@ def make_case(ref, name):
           f"strehl_last={out['s%d_strehl' % s0][-1]:.4f} res_last={out['s%d_residual' % s0][-1]:.1f} nm")
 
 
+def make_detector(ref):
+    """The reference's Detector (OOPAO/Detector.py) on a fixed synthetic frame, its four wall-clock seeded RandomStates
+    replaced by known seeds: Razor camera settings (MAIN/OOPAOEnv/OOPAOEnvRazor.py:243-250, 333) and three partial ones."""
+    from numpy.random import RandomState
+    rs = RandomState(5)
+    frame = rs.gamma(0.6, 400.0, size=(24, 24))                 # photons per pixel: mostly faint, a few bright spots
+    frame[3, 4] = 30000.0                                        # one pixel beyond the full-well capacity
+    out = {"frame": frame}
+    cases = {
+        "razor": dict(photonNoise=True, readoutNoise=14, QE=0.56, darkCurrent=5, integrationTime=1 / 500, FWC=10000, bits=10,
+                      sensor="CMOS"),
+        "photon_only": dict(photonNoise=True, readoutNoise=0, QE=1, darkCurrent=0, integrationTime=None, FWC=None, bits=None,
+                            sensor="CCD"),
+        "adc_only": dict(photonNoise=False, readoutNoise=0, QE=0.56, darkCurrent=0, integrationTime=None, FWC=10000, bits=10,
+                         sensor="CMOS"),
+        "readout_only": dict(photonNoise=False, readoutNoise=3.5, QE=0.9, darkCurrent=0, integrationTime=None, FWC=None,
+                             bits=None, sensor="CCD"),
+    }
+    for name, c in cases.items():
+        with RL.quiet():
+            det = ref.Detector(24, integrationTime=c["integrationTime"], bits=c["bits"], FWC=c["FWC"], sensor=c["sensor"],
+                               QE=c["QE"], darkCurrent=c["darkCurrent"], readoutNoise=c["readoutNoise"],
+                               photonNoise=c["photonNoise"])
+        det.random_state_photon_noise = RandomState(11)
+        det.random_state_readout_noise = RandomState(12)
+        det.random_state_dark_shot_noise = RandomState(13)
+        if c["integrationTime"] is not None:
+            det._integrated_time = c["integrationTime"]          # one frame per read-out, as wfs*cam does each loop step
+        with RL.quiet():
+            det.integrate(frame.copy())
+        out[name] = np.asarray(det.frame, dtype=np.float64)
+    path = os.path.join(GOLD, "detector.npz")
+    np.savez_compressed(path, **out)
+    print(f"detector: wrote {path}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -220,6 +256,8 @@ def main():
         if args.only and name != args.only:
             continue
         make_case(ref, name)
+    if args.only in (None, "detector"):
+        make_detector(ref)
 
 
 if __name__ == "__main__":

@@ -32,6 +32,12 @@ class AoCfg(C.Structure):
             "atm_wavelength", "src_wavelength", "leak", "threshold_cog")]
 
 
+class AoDetector(C.Structure):
+    _fields_ = [("photon_noise", C.c_int32), ("bits", C.c_int32), ("emccd", C.c_int32), ("env_index_offset", C.c_int32),
+                ("qe", C.c_double), ("dark_electrons", C.c_double), ("fwc", C.c_double), ("gain", C.c_double),
+                ("readout_noise", C.c_double), ("seed", C.c_uint64)]
+
+
 EXPORTS = {
     # name: (restype, argtypes)
     "aoenv_last_error": (C.c_char_p, []),
@@ -51,6 +57,7 @@ EXPORTS = {
                              C.c_void_p]),
     "aoenv_run_integrator": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p]),
+    "aoenv_set_detector": (C.c_int, [C.c_void_p, C.c_void_p]),
     "aoenv_set_return_accumulator": (C.c_int, [C.c_void_p, C.c_void_p]),
     "aoenv_buffer": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "aoenv_download": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),

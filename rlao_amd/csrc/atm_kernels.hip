@@ -117,16 +117,16 @@ __device__ inline void mt_normal_body(uint32_t* __restrict__ mt_state, int* __re
                 n1 = f * x1;                                      // cached, returned next
             }
         }
-        // inclusive scan of the accept flags over the workgroup
-        scan[t] = acc;
+        // inclusive scan of the accept flags over the workgroup: ballot + popcount inside a wave, 4 wave totals in LDS
+        const unsigned long long bal = __ballot(acc);
+        const int lane = t & (kWave - 1), wv = t / kWave;
+        const int in_wave = __popcll(bal & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull)));
+        if (lane == 0) scan[wv] = __popcll(bal);
         __syncthreads();
-        for (int off = 1; off < 256; off <<= 1) {
-            int v = (t >= off) ? scan[t - off] : 0;
-            __syncthreads();
-            scan[t] += v;
-            __syncthreads();
-        }
-        const int incl = scan[t];
+        int before = 0;
+        for (int q = 0; q < wv; ++q) before += scan[q];
+        const int total_acc = scan[0] + scan[1] + scan[2] + scan[3];
+        const int incl = before + in_wave;
         const int remaining = need_pairs - got;
         if (t == 0) sh_stop = -1;
         __syncthreads();
@@ -137,7 +137,6 @@ __device__ inline void mt_normal_body(uint32_t* __restrict__ mt_state, int* __re
             if (incl == remaining) sh_stop = t;                  // the attempt that completes the request
         }
         __syncthreads();
-        const int total_acc = scan[255];
         if (sh_stop >= 0) {
             if (t == 0) sh_pos = pos + 4 * (sh_stop + 1);
             break;

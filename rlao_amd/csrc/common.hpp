@@ -212,7 +212,9 @@ struct PyrSlopeArgs {
     T units;
 };
 template <typename T>
-int launch_pyramid(const PyrArgs<T>& base, const PyrSlopeArgs<T>& sl, int n_theta, int chunk, hipStream_t st);
+int launch_pyramid(const PyrArgs<T>& base, int n_theta, int chunk, hipStream_t st);      // camera frame only
+template <typename T>
+int launch_pyramid_slopes(const PyrSlopeArgs<T>& sl, int n_env, hipStream_t st);
 
 // ---- episode reset: von Karman screens on the device (screen_kernels.hip) ---------------------------------
 struct ScreenArgs {

@@ -7,6 +7,7 @@
 #include <new>
 
 #include "common.hpp"
+#include "detector.hpp"
 
 namespace ao {
 
@@ -99,6 +100,7 @@ struct AoEnv {
     int pyr_chunk = 1;
     void* vbuf = nullptr;                   // [E][A]
     void* obs_scratch = nullptr;            // [E][nAct*nAct]
+    DetectorCfg det{};                      // aoenv_set_detector(); det.active = 0: ideal camera
     void* ret_acc = nullptr;                // caller-owned [E] episode-return accumulator (aoenv_set_return_accumulator)
     std::vector<void*> allocs;
     // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
@@ -289,6 +291,15 @@ int run_phase(AoEnv* env, int update_atm, int store_atm, hipStream_t st, int sto
                            (env->use_mfma ? 1 : 0) | (env->debug_ablate << 8), st);
 }
 
+// the WFS camera on the frame in HBM (detector.hpp); every measurement is a new frame of the noise streams
+template <typename T>
+int apply_detector(AoEnv* env, bool sh, hipStream_t st) {
+    if (!env->det.active) return 0;
+    env->det.frame_counter += 1;
+    return launch_detector<T>(env->as<T>(env->frame), env->as<T>(env->wfs_max), sh ? env->valid2d : nullptr, env->E,
+                              env->c.cam_res, env->nSub, env->det, st);
+}
+
 template <typename T>
 int run_wfs(AoEnv* env, hipStream_t st) {
     if (env->c.wfs_type == AOENV_WFS_PYRAMID) {
@@ -323,7 +334,9 @@ int run_wfs(AoEnv* env, hipStream_t st) {
         sl.norm_valid_mean = env->c.pyr_norm_valid;
         sl.units = (T)env->units;
         AO_PROF(env, PYRAMID, st);
-        return launch_pyramid<T>(pa, sl, env->c.pyr_n_theta, env->pyr_chunk, st);
+        AO_TRY(launch_pyramid<T>(pa, env->c.pyr_n_theta, env->pyr_chunk, st));
+        AO_TRY(apply_detector<T>(env, false, st));                 // self*self.cam (OOPAO/Pyramid.py:987-1006)
+        return launch_pyramid_slopes<T>(sl, env->E, st);
     }
     const ShConst<T> sc = sh_const<T>(env);
     {
@@ -331,6 +344,7 @@ int run_wfs(AoEnv* env, hipStream_t st) {
         AO_TRY(launch_sh_spots<T>(env->as<T>(env->phase), sc, env->as<T>(env->frame), env->as<T>(env->wfs_max), env->E,
                                   env->R, env->nSub, env->nVal, st));
     }
+    AO_TRY(apply_detector<T>(env, true, st));                      // self*self.cam (OOPAO/ShackHartmann.py:576)
     {
         AO_PROF(env, SH_CENTROID, st);
         AO_TRY(launch_sh_centroid<T>(env->as<T>(env->frame), env->as<T>(env->wfs_max), sc, env->as<T>(env->signal),
@@ -399,7 +413,7 @@ bool fused_step_ok(const AoEnv*) { return false; }
 template <>
 bool fused_step_ok<float>(const AoEnv* env) {
     return env->use_fused_step && env->use_fast_wfs && env->use_mfma && env->use_fused_tail && env->c.wfs_type == AOENV_WFS_SH && env->c.dm_separable && env->n_modes > 0 &&
-           env->c.max_group == 1 && env->L > 0 && env->c.cam_res == env->R && env->debug_ablate == 0 &&
+           env->c.max_group == 1 && env->L > 0 && env->c.cam_res == env->R && env->debug_ablate == 0 && !env->det.active &&
            step_fused_supported(env->R, env->nSub, env->nVal, env->nAct, env->n_modes) != 0;
 }
 
@@ -509,6 +523,7 @@ int step_t(AoEnv* env, int i, const void* d_action, void* d_obs, void* d_frame, 
             AO_TRY(launch_sh_spots<T>(env->as<T>(env->phase), sc, env->as<T>(env->frame), env->as<T>(env->wfs_max), env->E,
                                       env->R, env->nSub, env->nVal, st));
         }
+        AO_TRY(apply_detector<T>(env, true, st));
         FinishArgs<T> fa = finish_args<T>(env, static_cast<const T*>(d_action), static_cast<T*>(d_obs),
                                           static_cast<T*>(d_reward), static_cast<T*>(d_strehl), i, 1, gain, 1);
         int rc;
@@ -1086,6 +1101,35 @@ int aoenv_run_integrator(AoEnv* env, int i0, int n_steps, double gain, void* d_o
     for (int k = 0; k < n_steps; ++k)
         AO_TRY(AO_DISPATCH(env, step_t, env, i0 + k, d_obs /*unused*/, d_obs, k == n_steps - 1 ? d_frame : nullptr, d_reward,
                            d_strehl, gain, st));
+    return 0;
+}
+
+int aoenv_set_detector(AoEnv* env, const AoDetector* cfg) {
+    AO_CHECK_ENV(env);
+    DetectorCfg d{};
+    if (cfg) {
+        if (cfg->bits < 0 || cfg->bits > 24) return fail("detector: bits %d outside [0, 24]", cfg->bits);
+        if (cfg->bits > 0 && !(cfg->fwc > 0)) return fail("detector: the ADC needs a full-well capacity (FWC = None with bits set is not built)");
+        if (!(cfg->qe > 0) || !(cfg->gain > 0) || cfg->dark_electrons < 0 || cfg->readout_noise < 0 || cfg->fwc < 0)
+            return fail("detector: QE and gain must be positive, dark current / read-out noise / FWC non-negative");
+        d.active = 1;
+        d.photon_noise = cfg->photon_noise != 0;
+        d.bits = cfg->bits;
+        d.emccd = cfg->emccd != 0;
+        d.qe = (float)cfg->qe;
+        d.dark_e = (float)cfg->dark_electrons;
+        d.fwc = (float)cfg->fwc;
+        d.gain = (float)cfg->gain;
+        d.readout_noise = (float)cfg->readout_noise;
+        d.seed_lo = (uint32_t)(cfg->seed & 0xffffffffu);
+        d.seed_hi = (uint32_t)(cfg->seed >> 32);
+        d.env_offset = (uint32_t)cfg->env_index_offset;
+        d.frame_counter = 0;
+        // identity settings are the ideal camera: keep the fast paths
+        if (!d.photon_noise && d.bits == 0 && d.qe == 1.f && d.dark_e == 0.f && d.fwc == 0.f && d.gain == 1.f && d.readout_noise == 0.f)
+            d.active = 0;
+    }
+    env->det = d;
     return 0;
 }
 

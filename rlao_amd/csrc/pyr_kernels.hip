@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(256) k_pyr_slopes(const PyrSlopeArgs<T> a) {
 }
 
 template <typename T>
-int launch_pyramid(const PyrArgs<T>& base, const PyrSlopeArgs<T>& sl, int n_theta, int chunk, hipStream_t st) {
+int launch_pyramid(const PyrArgs<T>& base, int n_theta, int chunk, hipStream_t st) {
     PyrArgs<T> a = base;
     const int N = a.N, R = a.R;
     // sequences per workgroup: keep the two LDS buffers within 64 KiB (P3 may need more: raised explicitly)
@@ -189,13 +189,20 @@ int launch_pyramid(const PyrArgs<T>& base, const PyrSlopeArgs<T>& sl, int n_thet
         hipLaunchKernelGGL(k_pyr_rows_inv<T>, dim3(a.cam, a.n_env), dim3(256), lds3, st, a, t0 > 0 ? 1 : 0);
         AO_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_pyr_slopes<T>, dim3(a.n_env), dim3(256), 0, st, sl);
-    AO_HIP(hipGetLastError());
     return 0;
 }
 
-template int launch_pyramid<float>(const PyrArgs<float>&, const PyrSlopeArgs<float>&, int, int, hipStream_t);
-template int launch_pyramid<double>(const PyrArgs<double>&, const PyrSlopeArgs<double>&, int, int, hipStream_t);
+template <typename T>
+int launch_pyramid_slopes(const PyrSlopeArgs<T>& sl, int n_env, hipStream_t st) {
+    hipLaunchKernelGGL(k_pyr_slopes<T>, dim3(n_env), dim3(256), 0, st, sl);
+    AO_HIP(hipGetLastError());
+    return 0;
+}
+template int launch_pyramid_slopes<float>(const PyrSlopeArgs<float>&, int, hipStream_t);
+template int launch_pyramid_slopes<double>(const PyrSlopeArgs<double>&, int, hipStream_t);
+
+template int launch_pyramid<float>(const PyrArgs<float>&, int, int, hipStream_t);
+template int launch_pyramid<double>(const PyrArgs<double>&, int, int, hipStream_t);
 
 // radix list for the Stockham transform: 4s first, then 2, 3, 5, then whatever prime factors remain
 int make_fft_plan(int n, FftPlan* pl) {

@@ -217,10 +217,23 @@ class _DmProxy:
 
 
 class _Cam:
+    """``env.wfs.cam``: the WFS detector settings of OOPAO/Detector.py (``photonNoise, readoutNoise, QE, darkCurrent,
+    integrationTime, FWC, bits, gain, sensor``).  Assigning one pushes the whole camera model to the device
+    (``aoenv_set_detector``); the frame of every later measurement goes through it before the slopes are computed."""
+    _FIELDS = dict(photonNoise=False, readoutNoise=0, QE=1, darkCurrent=0, integrationTime=None, FWC=None, bits=None, gain=1,
+                   sensor="CCD")
+
     def __init__(self, env):
-        self._e = env
-        self.photonNoise = False
-        self.readoutNoise = 0
+        object.__setattr__(self, "_e", env)
+        for k, v in self._FIELDS.items():
+            object.__setattr__(self, k, v)
+
+    def __setattr__(self, name, value):
+        if name == "sensor" and value not in ("EMCCD", "CCD", "CMOS"):
+            raise ValueError("Sensor must be 'EMCCD', 'CCD', or 'CMOS'")          # OOPAO/Detector.py:40-41
+        object.__setattr__(self, name, value)
+        if name in self._FIELDS:
+            self._e._push_detector()
 
     @property
     def frame(self):
@@ -326,6 +339,7 @@ class BatchedAOEnv:
         self.return_frame = return_frame
         self.env_seed_stride = int(env_seed_stride)
         self.env_index_offset = int(env_index_offset)
+        self.detector_seed = 0
         # attributes of the reference env (MAIN/OOPAOEnv/OOPAOEnv.py:19-72)
         self.gainCL = None
         self.net_gain = 0.5
@@ -545,6 +559,18 @@ class BatchedAOEnv:
     def _fetch(self, which, shape):
         out = self._shard.download(which, (self.n_envs,) + tuple(shape), self._stream())
         return out[0] if self.n_envs == 1 else out
+
+    def _push_detector(self):
+        """wfs.cam.* -> aoenv_set_detector (OOPAO/Detector.py:232-301).  ``detector_seed`` keys the noise streams."""
+        if self._shard is None or self.wfs is None:
+            return
+        cam = self.wfs.cam
+        t_int = cam.integrationTime if cam.integrationTime is not None else self.param.samplingTime
+        d = L.AoDetector(photon_noise=int(bool(cam.photonNoise)), bits=int(cam.bits or 0), emccd=int(cam.sensor == "EMCCD"),
+                         env_index_offset=int(self.env_index_offset), qe=float(cam.QE),
+                         dark_electrons=float(cam.darkCurrent) * float(t_int), fwc=float(cam.FWC or 0), gain=float(cam.gain),
+                         readout_noise=float(cam.readoutNoise), seed=int(self.detector_seed) & 0xFFFFFFFFFFFFFFFF)
+        L.check(self._shard.lib.aoenv_set_detector(self._shard.h, C.byref(d)))
 
     def _push_wind(self, reset: bool):
         p = self.param

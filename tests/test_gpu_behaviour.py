@@ -90,6 +90,21 @@ def test_run_integrator_equals_stepping():
     np.testing.assert_allclose(obs.cpu().numpy(), a[-1][0].cpu().numpy(), atol=1e-6)
     np.testing.assert_allclose(sr.cpu().numpy(), a[-1][3].cpu().numpy(), atol=1e-6)
     np.testing.assert_allclose(env.total[:10], env.total[:10])
+    # the on-device episode return (aoenv_set_return_accumulator) is the sum of the step rewards
+    ret = torch.zeros(4, device=env.device, dtype=env.tdtype)
+    env.generate_new_phase_screen(3)
+    env.dm.coefs = 0
+    env.measure()
+    env.reset_soft()
+    env.accumulate_returns(ret)
+    env.run_integrator(0, 10)
+    env.accumulate_returns(None)
+    env.run_integrator(10, 2)                                   # detached: not counted
+    torch.cuda.synchronize()
+    want = sum(step[2].double() for step in a)
+    np.testing.assert_allclose(ret.cpu().numpy(), want.cpu().numpy(), rtol=2e-6)
+    with pytest.raises(ValueError):
+        env.accumulate_returns(torch.zeros(3, device=env.device))
     env.close()
 
 

@@ -96,3 +96,24 @@ def test_closed_loop_replay(case):
                 np.testing.assert_allclose(env.tel_OPD, g[p + "opd_res"][k], atol=1e-18)
                 np.testing.assert_allclose(frame, g[p + "frame"][k], atol=1e-8 * g[p + "frame"][k].max())
                 assert done is False
+
+
+def test_detector_matches_reference(golden_dir):
+    """oracle.Detector == the reference's OOPAO/Detector.py (integrate + readout) bit for bit when both draw from the same
+    RandomStates: Razor camera (photon + dark + read-out noise, QE, saturation, 10-bit ADC) and three partial settings."""
+    from numpy.random import RandomState
+    g = np.load(os.path.join(golden_dir, "detector.npz"))
+    cases = {
+        "razor": dict(photonNoise=True, readoutNoise=14, QE=0.56, darkCurrent=5, integrationTime=1 / 500, FWC=10000, bits=10,
+                      sensor="CMOS"),
+        "photon_only": dict(photonNoise=True, readoutNoise=0, QE=1, darkCurrent=0, integrationTime=None, FWC=None, bits=None,
+                            sensor="CCD"),
+        "adc_only": dict(photonNoise=False, readoutNoise=0, QE=0.56, darkCurrent=0, integrationTime=None, FWC=10000, bits=10,
+                         sensor="CMOS"),
+        "readout_only": dict(photonNoise=False, readoutNoise=3.5, QE=0.9, darkCurrent=0, integrationTime=None, FWC=None,
+                             bits=None, sensor="CCD"),
+    }
+    for name, c in cases.items():
+        det = O.Detector(**c)
+        det.rs_photon, det.rs_readout, det.rs_dark = RandomState(11), RandomState(12), RandomState(13)
+        np.testing.assert_array_equal(det.integrate(g["frame"]), g[name], err_msg=name)
