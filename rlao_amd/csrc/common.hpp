@@ -95,7 +95,7 @@ struct PhaseBuffers {
     double* part;          // [E][tiles][4] per-tile Sum / Sum^2 of the atmosphere and residual OPD over the pupil
     T* wfs_max;            // [E] zeroed here for the WFS kernels
 };
-int phase_tiles(int R);
+int phase_tiles(int R, int n_act, size_t esz);
 template <typename T>
 struct KArgs {                 // kernel argument block of the phase kernels
     PhaseArgs pa;
@@ -158,6 +158,16 @@ template <typename T>
 int launch_sh_tail(const T* frame, const T* wfs_max, const ShConst<T>& sc, T* signal, const T* fac_m,
                    const T* fac_m2c_t, int n_modes, const FinishArgs<T>& fa, int n_env, int R, int n_subap, int n_valid,
                    int max_group, hipStream_t st);
+// WFS camera model (detector.hpp)
+struct DetectorCfg {           // by value into kernels
+    int active;                // 0: ideal detector (identity)
+    int photon_noise, bits, emccd;
+    float qe, dark_e, fwc, gain, readout_noise;     // fwc <= 0: no full-well capacity
+    uint32_t seed_lo, seed_hi;
+    uint32_t frame_counter;    // incremented by the host for every measurement
+    uint32_t env_offset;       // global index of env 0 of this shard
+};
+
 // fused per-env step kernel (step_kernel.hip): float32, 6 px per lenslet, separable DM, factored reconstructor
 struct StepArgs {
     KArgs<float> k;
@@ -172,6 +182,7 @@ struct StepArgs {
     const float* amp_pupil;      // [R*R] WFS field amplitude inside the pupil, -1 outside (pupil and amp in one load)
     const float* gxa;            // [128][4][8] gx[x][q + 4 s] at [x][q][s], zero padded: MFMA operands as two 16-byte loads
     const float* gya;            // [128][4][8] gy[y][q + 4 s]
+    DetectorCfg det;             // WFS camera (active = 0: ideal)
     int n_modes, n_subap, n_valid, n_env;
 };
 int step_fused_supported(int R, int n_subap, int n_valid, int n_act, int n_modes);

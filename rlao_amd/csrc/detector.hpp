@@ -14,15 +14,6 @@
 
 namespace ao {
 
-struct DetectorCfg {           // by value into kernels
-    int active;                // 0: ideal detector (identity)
-    int photon_noise, bits, emccd;
-    float qe, dark_e, fwc, gain, readout_noise;     // fwc <= 0: no full-well capacity
-    uint32_t seed_lo, seed_hi;
-    uint32_t frame_counter;    // incremented by the host for every measurement
-    uint32_t env_offset;       // global index of env 0 of this shard
-};
-
 struct Philox {
     uint32_t c[4], k[2];
     __device__ inline void round() {

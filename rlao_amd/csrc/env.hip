@@ -413,7 +413,7 @@ bool fused_step_ok(const AoEnv*) { return false; }
 template <>
 bool fused_step_ok<float>(const AoEnv* env) {
     return env->use_fused_step && env->use_fast_wfs && env->use_mfma && env->use_fused_tail && env->c.wfs_type == AOENV_WFS_SH && env->c.dm_separable && env->n_modes > 0 &&
-           env->c.max_group == 1 && env->L > 0 && env->c.cam_res == env->R && env->debug_ablate == 0 && !env->det.active &&
+           env->c.max_group == 1 && env->L > 0 && env->c.cam_res == env->R && env->debug_ablate == 0 &&
            step_fused_supported(env->R, env->nSub, env->nVal, env->nAct, env->n_modes) != 0;
 }
 
@@ -487,6 +487,8 @@ int run_fused_step<float>(AoEnv* env, int i, const void* d_action, void* d_obs, 
     a.amp_pupil = env->amp_pupil;
     a.gxa = env->gxa;
     a.gya = env->gya;
+    if (env->det.active) env->det.frame_counter += 1;              // every measurement is a new frame of the noise streams
+    a.det = env->det;
     a.n_modes = env->n_modes;
     a.n_subap = env->nSub;
     a.n_valid = env->nVal;
@@ -654,7 +656,7 @@ int aoenv_create(const AoCfg* cfg, int device, AoEnv** out) {
     A_(&e->coefs, E * e->A * z);
     A_(&e->phase, E * R2 * z);
     A_(&e->scal, E * 4 * z);
-    e->n_tiles = phase_tiles(e->R);
+    e->n_tiles = phase_tiles(e->R, e->nAct, e->esz);
     A_((void**)&e->part, E * (size_t)e->n_tiles * 4 * sizeof(double));
     A_(&e->total, (size_t)cfg->n_loop * E * z);
     A_(&e->residual, (size_t)cfg->n_loop * E * z);
@@ -1129,6 +1131,8 @@ int aoenv_set_detector(AoEnv* env, const AoDetector* cfg) {
         if (!d.photon_noise && d.bits == 0 && d.qe == 1.f && d.dark_e == 0.f && d.fwc == 0.f && d.gain == 1.f && d.readout_noise == 0.f)
             d.active = 0;
     }
+    if (env->det.active && !d.active)                              // no stale noise outside the valid lenslets
+        AO_HIP(hipMemset(env->frame, 0, (size_t)env->E * env->c.cam_res * env->c.cam_res * env->esz));
     env->det = d;
     return 0;
 }

@@ -376,9 +376,19 @@ int launch_phase_mfma<float>(const KArgs<float>& a, int n_env, hipStream_t st) {
     return 0;
 }
 
-int phase_tiles(int R) {
-    const int tx = R < kTXmax ? R : kTXmax;
-    return cdiv(R, tx) * cdiv(R, kTY);
+// Tile width of the generic kernel: as wide as its LDS image allows (command image + Gy C + Gx^T + two staged tiles);
+// large DMs in float64 (ELT calibration shards: 81 actuators across) take narrower tiles.
+static size_t phase_lds_bytes(int n_act, int tx, size_t esz) {
+    const int MW = tx + 4;
+    return esz * ((size_t)n_act * n_act + (size_t)kTY * n_act + (size_t)n_act * tx + (size_t)(kTY + 3) * MW + (size_t)(kTY + 3) * tx);
+}
+int phase_tx(int R, int n_act, size_t esz) {
+    int tx = R < kTXmax ? R : kTXmax;
+    while (tx > 16 && phase_lds_bytes(n_act, tx, esz) > 160 * 1024) tx = (tx + 1) / 2;
+    return tx;
+}
+int phase_tiles(int R, int n_act, size_t esz) {
+    return cdiv(R, phase_tx(R, n_act, esz)) * cdiv(R, kTY);
 }
 
 template <typename T>
@@ -390,7 +400,7 @@ KArgs<T> make_phase_kargs(const PhaseArgs& pa, const PhaseBuffers<T>& pb, int R,
     a.R = R;
     a.n_act = n_act;
     a.n_valid_act = n_valid_act;
-    a.tx = R < kTXmax ? R : kTXmax;
+    a.tx = phase_tx(R, n_act, sizeof(T));
     a.rp = cdiv(R, kTXmax) * kTXmax;
     a.ablate = 0;
     a.atm_scale = (T)(atm_wavelength / 2 / 3.14159265358979323846);
@@ -413,9 +423,8 @@ int launch_phase(const PhaseArgs& pa, const PhaseBuffers<T>& pb, int n_env, int 
             if (rc >= 0) return rc;
         }
     }
-    const int TX = a.tx, MW = TX + 4;
-    const size_t lds = sizeof(T) * ((size_t)n_act * n_act + (size_t)kTY * n_act + (size_t)n_act * TX +
-                                    (size_t)(kTY + 3) * MW + (size_t)(kTY + 3) * TX);
+    const int TX = a.tx;
+    const size_t lds = phase_lds_bytes(n_act, TX, sizeof(T));
     if (lds > 160 * 1024) return fail("phase kernel: %d actuators across need %zu B of LDS", n_act, lds);
     if (lds > 64 * 1024)
         AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_phase<T>), hipFuncAttributeMaxDynamicSharedMemorySize,

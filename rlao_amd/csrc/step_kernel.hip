@@ -31,6 +31,7 @@ namespace ao { __device__ unsigned long long g_stamps[1024 * 24]; }
 #endif
 
 #include "sh_device.hpp"
+#include "detector.hpp"
 
 namespace ao {
 
@@ -382,6 +383,16 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
         const int kk = a.sc.subap_idx[s];
         li = kk / n_sub;
         lj = kk - li * n_sub;
+        if (a.det.active) {                                      // self*self.cam: the camera on the lane's 12 pixels
+            const uint32_t q0 = (uint32_t)((li * 6) * R + lj * 6 + q3);
+#pragma unroll 1
+            for (int u = 0; u < 6; ++u) {
+                const float va = detector_pixel(Ia[u], a.det, q0 + (uint32_t)(u * R), (uint32_t)e);
+                const float vb = detector_pixel(Ib[u], a.det, q0 + (uint32_t)(u * R) + 3u, (uint32_t)e);
+                Ia[u] = va;
+                Ib[u] = vb;
+            }
+        }
         float* fr = a.frame + pix0 + (size_t)(li * 6) * R + lj * 6 + q3;
 #pragma unroll
         for (int u = 0; u < 6; ++u) {
@@ -392,6 +403,17 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
         }
     }
     AO_STAMP(15);
+    if (a.det.active) {
+        // the camera also reads out the pixels of the lenslets that are not valid (no light): dark + read-out noise, ADC
+        for (int idx = tid; idx < n_sub * n_sub * 36; idx += 1024) {
+            const int kk = idx / 36, pp = idx - 36 * kk;
+            if (slot_s[kk] < 0) {
+                const int i2 = kk / n_sub, j2 = kk - i2 * n_sub;
+                const uint32_t q = (uint32_t)((i2 * 6 + pp / 6) * R + j2 * 6 + pp % 6);
+                a.frame[pix0 + q] = detector_pixel(0.f, a.det, q, (uint32_t)e);
+            }
+        }
+    }
     for (int off = 32; off > 0; off >>= 1) {
         const float o = __shfl_down(mx, off);
         mx = o > mx ? o : mx;
