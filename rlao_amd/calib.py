@@ -420,9 +420,21 @@ def zernike_basis(pupil: np.ndarray, D: float, n_modes: int) -> np.ndarray:
 
 
 def zernike_m2c(dm: DMTables, pupil: np.ndarray, D: float, n_modes: int) -> np.ndarray:
-    """M2C = pinv(dm.modes[pupil]) @ Z.modes  (MAIN/OOPAOEnv/OOPAOEnv.py:258, OOPAOEnvRazor.py:261)."""
+    """M2C = pinv(dm.modes[pupil]) @ Z.modes  (MAIN/OOPAOEnv/OOPAOEnv.py:258, OOPAOEnvRazor.py:261).
+    Beyond ~2000 actuators (ELT: 5209 actuators x 181 k pupil pixels) the SVD behind ``pinv`` takes hours on the host:
+    the same least-squares problem is then solved on the GPU in float64 (one-off set-up work, not the step path)."""
     modes = dm.dense_modes()[pupil.reshape(-1)]
-    return np.linalg.pinv(modes) @ zernike_basis(pupil, D, n_modes)
+    Z = zernike_basis(pupil, D, n_modes)
+    if modes.shape[1] <= 2000:
+        return np.linalg.pinv(modes) @ Z
+    import torch
+    dev = "cuda" if torch.cuda.is_available() else "cpu"
+    A_ = torch.as_tensor(modes, device=dev)
+    # normal equations through a Cholesky factor of the (well conditioned: Gaussian influence functions, coupling 0.35) Gram matrix
+    G = A_.T @ A_
+    rhs = A_.T @ torch.as_tensor(Z, device=dev)
+    del A_
+    return torch.linalg.solve(G, rhs).cpu().numpy()
 
 
 def svd_inverse(D: np.ndarray) -> np.ndarray:
