@@ -46,9 +46,10 @@ __device__ inline float ld_or0(const P* __restrict__ p, long idx, bool ok) {
 }
 
 namespace fstep {
-constexpr int TX = 128, MW = TX + 4, PR = 64;          // tile width, staged row stride, rows per pass
-constexpr int MW4 = MW / 4;                            // float4 per staged row
-constexpr int NV4 = ((PR + 3) * MW4 + 1023) / 1024;    // 16-byte staging loads per lane and layer
+constexpr int TX = 128, PR = 64;                       // widest pupil, rows per pass
+constexpr int WR = 16 + 3, WC = 32 + 4;                // a wave's private layer tile: 19 rows x 35 columns (stride 36)
+constexpr int WC4 = WC / 4;                            // float4 per staged row of the wave tile
+constexpr int NV4 = (WR * WC4 + 63) / 64;              // 16-byte staging loads per lane and layer
 }  // namespace fstep
 
 struct StepLds {
@@ -63,7 +64,7 @@ static StepLds step_lds_layout(int n_act, int n_subap, int n_valid, int n_modes)
     auto take = [&](int words) { const int at = o; o += (words + 3) & ~3; return at; };
     L.cimg = take(n_act * n_act);
     L.s1 = take(2 * PR * SS);
-    L.mapt = take((PR + 3) * MW);
+    L.mapt = take(16 * WR * WC);
     L.slot = take((n_subap * n_subap + 1) / 2);
     L.e0 = take(2 * n_valid * fast6::EST);
     L.sl = take(2 * n_valid);
@@ -84,7 +85,8 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
     const int nAp = (nA + 3) & ~3, SS = nAp + 1;
     float* cimg = lds + L.cimg;                                  // [nA][nA] command image
     float* s1 = lds + L.s1;                                      // [2 PR][SS]  Gy C, every row
-    float* mapt = lds + L.mapt;                                  // [PR + 3][MW] staged layer tile (also the Gy rows)
+    const int w_ = threadIdx.x >> 6;
+    float* mapt = lds + L.mapt + w_ * (WR * WC);                   // [WR][WC] this wave's private layer tile
     short* slot_s = reinterpret_cast<short*>(lds + L.slot);      // [nSub^2] lenslet -> compact valid index or -1
     cplx<float>* E0 = reinterpret_cast<cplx<float>*>(lds + L.e0);    // [nValid][EST]
     float* sl = lds + L.sl;                                      // [2 nValid] slopes
@@ -211,7 +213,7 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
         const int tye = min(PR, R - y0);
         const int yl = 16 * band + lc, y = y0 + yl;              // the lane's row
         const bool row_ok = yl < tye;
-        lds_barrier();                                           // s1 complete / previous pass done with mapt
+        if (pass == 0) lds_barrier();                            // s1 and the screen ranges complete
         AO_STAMP(1 + 6 * pass);
         // pupil + WFS amplitude of the lane's 2 x 4 pixels (one table: amplitude, or -1 outside the pupil), long before use
         f32x4s apv[2];
@@ -231,17 +233,22 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
             const LayerTaps& tp = k.pa.taps[l];
             const float* map = static_cast<const float*>(k.pa.screen[l]) + (size_t)e * S * S;
             const int r0 = y0 + k.pa.foot + tp.dy - 1, c0 = k.pa.foot + tp.dx - 1;
-            lds_barrier();                                       // the previous layer's tile is no longer read
+            // Every wave stages ITS tile (16 rows x 32 columns + the 4 x 4 stencil apron) in a private LDS slice: no
+            // workgroup barrier in the atmosphere / DM part, so the 16 waves drift apart and one wave's loads overlap
+            // another's arithmetic.  LDS operations of one wave execute in order: a compiler fence is all that is needed
+            // between the tile writes and the reads of other lanes' data.
+            asm volatile("" ::: "memory");
             AO_STAMP(3 + 6 * pass);
             {
-                // tile element (r, c) = map[r0 + r][c0 + c], r < tye + 3, c < R + 3; staged as rows of MW4 float4
+                // tile element (r, c) = map[r0 + 16 band + r][c0 + 32 cg + c], staged as rows of WC4 float4
+                const int rw0 = r0 + 16 * band, cw0 = c0 + 32 * cg;
                 f32x4s v[NV4];
 #pragma unroll
                 for (int q = 0; q < NV4; ++q) {
-                    const int idx = tid + 1024 * q;
-                    const int r = idx / MW4, c = 4 * (idx - r * MW4);
-                    const int rr = r0 + r, cc = c0 + c;
-                    const bool need = idx < (PR + 3) * MW4 && r < tye + 3 && c < R + 3 && rr >= 0 && rr < S && cc >= 0 && cc < S;
+                    const int idx = lane + 64 * q;
+                    const int r = idx / WC4, c = 4 * (idx - r * WC4);
+                    const int rr = rw0 + r, cc = cw0 + c;
+                    const bool need = idx < WR * WC4 && 16 * band + r < tye + 3 && 32 * cg + c < R + 3 && rr >= 0 && rr < S && cc >= 0 && cc < S;
                     int pr = rr + tp.oy, pc = cc + tp.ox;         // torus: physical = (logical + origin) mod S
                     pr = pr >= S ? pr - S : pr;
                     pc = pc >= S ? pc - S : pc;
@@ -262,11 +269,11 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
                 }
 #pragma unroll
                 for (int q = 0; q < NV4; ++q) {
-                    const int idx = tid + 1024 * q;
-                    if (idx < (PR + 3) * MW4) *reinterpret_cast<f32x4s*>(mapt + 4 * idx) = v[q];
+                    const int idx = lane + 64 * q;
+                    if (idx < WR * WC4) *reinterpret_cast<f32x4s*>(mapt + 4 * idx) = v[q];
                 }
             }
-            lds_barrier();
+            asm volatile("" ::: "memory");
             AO_STAMP(4 + 6 * pass);
             const float wx0 = (float)tp.wx[0], wx1 = (float)tp.wx[1], wx2 = (float)tp.wx[2], wx3 = (float)tp.wx[3];
             const float wy0 = (float)tp.wy[0], wy1 = (float)tp.wy[1], wy2 = (float)tp.wy[2], wy3 = (float)tp.wy[3];
@@ -274,12 +281,12 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
             const bool zero_outside = (lo > 0.f || hi < 0.f);
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
-                const int xt = 16 * (2 * cg + tt) + 4 * lq;       // tile column of the first tap of the lane's first pixel
+                const int xt = 16 * tt + 4 * lq;                  // wave-tile column of the first tap of the lane's first pixel
                 // the 4 rows x 8 columns of taps (7 used) as 16-byte LDS reads; horizontal pass per row, then vertical
                 float h[4][4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float* m = mapt + (yl + q) * MW + xt;
+                    const float* m = mapt + (lc + q) * WC + xt;
                     const f32x4s m0 = *reinterpret_cast<const f32x4s*>(m), m1 = *reinterpret_cast<const f32x4s*>(m + 4);
                     const float t[7] = {m0[0], m0[1], m0[2], m0[3], m1[0], m1[1], m1[2]};
 #pragma unroll
@@ -294,7 +301,6 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
                 }
             }
         }
-        lds_barrier();                                           // (only needed when there is no layer)
         AO_STAMP(5 + 6 * pass);
 
         // ---- DM surface on the matrix cores, pupil, phase store, E0 -> LDS, telemetry sums -----------------------------
