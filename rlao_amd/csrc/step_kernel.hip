@@ -24,10 +24,12 @@
 
 // Diagnostic build only (-DAO_STEP_STAMPS): wave 0 of each workgroup stamps s_memtime at the stage boundaries.
 #ifdef AO_STEP_STAMPS
-namespace ao { __device__ unsigned long long g_stamps[1024 * 24]; }
+namespace ao { __device__ unsigned long long g_stamps[1024 * 24]; __device__ unsigned long long g_wstamps[256 * 16 * 8]; }
+#define AO_WSTAMP(i) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 256) ::ao::g_wstamps[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define AO_STAMP(i) do { if (tid == 0 && e < 1024) ::ao::g_stamps[e * 24 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define AO_STAMP(i) do { } while (0)
+#define AO_WSTAMP(i) do { } while (0)
 #endif
 
 #include "sh_device.hpp"
@@ -103,6 +105,7 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
     const int n_sub = a.n_subap, n_valid = a.n_valid;
 
     AO_STAMP(0);
+    AO_WSTAMP(0);
     // ---- prologue: every global load of the prologue is issued before the first barrier ------------------------------------
     // (the barriers are compiler fences for memory operations: a load written after one is issued after it)
     // A operands of the DM product, Gx[x][k = lane >> 4 + 4 step]: the lane's two column tiles are the same in every
@@ -121,6 +124,10 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
         gy_raw[0] = src[0];
         gy_raw[1] = src[1];
     }
+    float mm_pre[kMaxLayer];                                     // stored range of every layer's screen (lane & 1: min / max)
+#pragma unroll
+    for (int l = 0; l < kMaxLayer; ++l)
+        mm_pre[l] = l < k.pa.n_layer ? static_cast<const float*>(k.pa.minmax[l])[2 * e + (tid & 1)] : 0.f;
     const bool has_act = tid < k.n_valid_act;                    // n_valid_act <= 1024 (n_act <= 32)
     const int act_px = k.pb.act_idx[has_act ? tid : 0];
     const float act_c = k.pb.coefs[(size_t)e * k.n_valid_act + (has_act ? tid : 0)];
@@ -132,6 +139,12 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
     for (int i = tid + 1024; i < n_sub * n_sub; i += 1024) slot_s[i] = a.slot_of[i];
     lds_barrier();
     if (has_act) cimg[act_px] = act_c;
+    // the integrator's input of this lane's actuator (previous observation, or the caller's action): needed only in stage C
+    float act_prev = 0.f;
+    if (a.fa.do_integrate) {
+        const size_t io = (size_t)e * (nA * nA) + (has_act ? act_px : 0);
+        act_prev = (a.fa.gain_from_obs != 0.f) ? a.fa.obs[io] : a.fa.action[io];
+    }
     float breg[2][KS];
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
@@ -171,7 +184,10 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
     for (int l = 0; l < k.pa.n_layer; ++l) {
         float* mm = const_cast<float*>(static_cast<const float*>(k.pa.minmax[l])) + 2 * e;
         if (!k.pa.minmax_dirty[l]) {
-            if (tid < 2) lohi[l][tid] = mm[tid];
+            float pre = 0.f;
+#pragma unroll
+            for (int q = 0; q < kMaxLayer; ++q) pre = q == l ? mm_pre[q] : pre;
+            if (tid < 2) lohi[l][tid] = pre;
             continue;
         }
         // the torus is a permutation of the (N+2)^2 pixels: scan it physically with 16-byte loads
@@ -213,7 +229,7 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
         const int tye = min(PR, R - y0);
         const int yl = 16 * band + lc, y = y0 + yl;              // the lane's row
         const bool row_ok = yl < tye;
-        if (pass == 0) lds_barrier();                            // s1 and the screen ranges complete
+        if (pass == 0) { AO_WSTAMP(1); lds_barrier(); AO_WSTAMP(2); }   // s1 and the screen ranges complete
         AO_STAMP(1 + 6 * pass);
         // pupil + WFS amplitude of the lane's 2 x 4 pixels (one table: amplitude, or -1 outside the pupil), long before use
         f32x4s apv[2];
@@ -350,6 +366,7 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
         }
     }
     AO_STAMP(13);
+    AO_WSTAMP(3);
     // telemetry: waves in a fixed order
     s_atm = wave_sum_f64(s_atm);
     q_atm = wave_sum_f64(q_atm);
@@ -363,6 +380,7 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
     }
     lds_barrier();                                             // E0 complete, red complete
     AO_STAMP(14);
+    AO_WSTAMP(4);
     if (tid == 1023) {                                           // an idle lane: runs beside the spots of the other waves
         double v[4];
         for (int c = 0; c < 4; ++c) {
@@ -420,11 +438,27 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
             }
         }
     }
+    // Stage C operands that do not depend on the slopes are requested now: the rows of M (16 lanes per mode, 16-byte
+    // loads) and the reference slopes; their latency overlaps the threshold barrier and the centre of gravity.
+    // (an opaque zero in the address pins these loads here: loads from read-only kernel arguments may otherwise be
+    //  hoisted to the top of the kernel, where 40 more live registers spill)
+    int late0;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(late0) : "v"(mx));
+    const int n_sig = 2 * n_valid, n4 = n_sig / 4, A = k.n_valid_act;
+    const int km = tid >> 4, l16 = tid & 15;                     // (host: n_modes <= 52, nSig % 4 == 0, nSig <= 640)
+    f32x4s mv[10];
+    {
+        const f32x4s* row = reinterpret_cast<const f32x4s*>(a.fac_m + (size_t)(km < a.n_modes ? km : 0) * n_sig);
+#pragma unroll
+        for (int j = 0; j < 10; ++j) mv[j] = row[(l16 + 16 * j < n4 ? l16 + 16 * j : 0) + late0];
+    }
+    const float ref0 = a.sc.ref[ok ? s : 0], ref1 = a.sc.ref[ok ? n_valid + s : 0];
     for (int off = 32; off > 0; off >>= 1) {
         const float o = __shfl_down(mx, off);
         mx = o > mx ? o : mx;
     }
     if (lane == 0) red_mx[w] = mx;
+    AO_WSTAMP(5);
     lds_barrier();
     AO_STAMP(16);
     mx = red_mx[0];
@@ -451,7 +485,7 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
                 c0 = m0 / norm;
                 c1 = m1 / norm;
             }
-            const float v0 = (c0 - a.sc.ref[s]) / a.sc.units, v1 = (c1 - a.sc.ref[n_valid + s]) / a.sc.units;
+            const float v0 = (c0 - ref0) / a.sc.units, v1 = (c1 - ref1) / a.sc.units;
             sl[s] = v0;
             sl[n_valid + s] = v1;
             a.signal[(size_t)e * 2 * n_valid + s] = v0;
@@ -462,11 +496,87 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
     AO_STAMP(17);
 
     // ---- stage C ------------------------------------------------------------------------------------------------------------
-    tail_from_slopes<float, false>(sl, img_s, red_tail, a.fac_m, a.fac_m2c_t, a.n_modes, a.fa, e, n_valid, a.n_env);
+    // Same arithmetic as tail_from_slopes (sh_device.hpp), with every operand that does not depend on the slopes already
+    // in registers: t = M s ; o = -M2C t 1e6 ; integrator ; obs image ; reward          (MAIN/OOPAOEnv/OOPAOEnv.py:491-536)
+    const int img = nA * nA;
+    float* tm = img_s + img;                                     // [K] modal coefficients
+    {
+        const f32x4s* s4 = reinterpret_cast<const f32x4s*>(sl);
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+            const bool okj = l16 + 16 * j < n4;
+            const f32x4s sv = s4[okj ? l16 + 16 * j : 0];
+            const float d = ((mv[j][0] * sv[0] + mv[j][1] * sv[1]) + mv[j][2] * sv[2]) + mv[j][3] * sv[3];
+            acc += okj ? d : 0.f;
+        }
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 16);
+        if (km < a.n_modes && l16 == 0) tm[km] = acc;
+    }
+    // M2C^T rows for the lane's group of 4 actuators (4 lanes per group, lane part p takes the modes p, p + 4, ...):
+    // requested before the barrier, they do not depend on t
+    const int n_grp = (A + 3) / 4, g = tid >> 2, part = tid & 3;
+    const bool g_ok = g < n_grp;
+    f32x4s cv[13];
+    int late1;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(late1) : "v"(late0));
+#pragma unroll
+    for (int j = 0; j < 13; ++j)
+        __builtin_memcpy(&cv[j], a.fac_m2c_t + (part + 4 * j < a.n_modes ? (size_t)(part + 4 * j) * A + 4 * (g_ok ? g : 0) : 0) + late1, 16);
+    lds_barrier();
+    AO_STAMP(19);
+    double ss = 0.0;
+    {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 13; ++j) {
+            const bool okj = part + 4 * j < a.n_modes;
+            const float t = tm[okj ? part + 4 * j : 0];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) acc[d] += okj ? cv[j][d] * t : 0.f;
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            acc[d] += __shfl_xor(acc[d], 1, 4);
+            acc[d] += __shfl_xor(acc[d], 2, 4);
+        }
+        // lane tid finishes actuator k = tid (= 4 g + part): its command, image index and integrator input are in registers
+        if (has_act) {
+            const float mine = part == 0 ? acc[0] : (part == 1 ? acc[1] : (part == 2 ? acc[2] : acc[3]));
+            if (a.fa.do_integrate) {
+                const float act = (a.fa.gain_from_obs != 0.f) ? a.fa.gain_from_obs * act_prev : act_prev;
+                a.fa.coefs[(size_t)e * A + tid] = act_c * a.fa.leak + act * 1e-6f;      // float32 increment (k_recon_finish)
+            }
+            const float o = -mine * 1e6f;
+            img_s[act_px] = o;
+            ss += (double)o * (double)o;
+        }
+    }
+    lds_barrier();
+    AO_STAMP(20);
+    {
+        float* ob = a.fa.obs + (size_t)e * img;
+        for (int q = tid; q < img; q += 1024) ob[q] = img_s[q];
+    }
+    ss = wave_sum_f64(ss);
+    if (lane == 0) red_tail[w] = ss;
+    lds_barrier();
+    AO_STAMP(21);
+    if (tid == 0) {
+        double tot = 0;
+        for (int q = 0; q < 16; ++q) tot += red_tail[q];
+        if (a.fa.reward) a.fa.reward[e] = (float)(-sqrt(tot));
+        if (a.fa.ret && a.fa.do_integrate) a.fa.ret[e] += (float)(-sqrt(tot));
+    }
     AO_STAMP(18);
+    AO_WSTAMP(6);
 }
 
 #ifdef AO_STEP_STAMPS
+extern "C" int aoenv_debug_wstamps(unsigned long long* h_out) {
+    return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_wstamps), sizeof(unsigned long long) * 256 * 16 * 8) == hipSuccess ? 0 : 1;
+}
 extern "C" int aoenv_debug_stamps(unsigned long long* h_out, int n_env) {
     return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 24 * (size_t)n_env) == hipSuccess ? 0 : 1;
 }
@@ -476,7 +586,7 @@ int step_fused_supported(int R, int n_subap, int n_valid, int n_act, int n_modes
     if (R % n_subap || R / n_subap != fast6::P) return 0;
     if (R > fstep::TX || R % 4) return 0;
     if (n_valid > 16 * 21 || n_subap * n_subap > 32767 || n_act > 32) return 0;
-    if (n_modes < 1) return 0;
+    if (n_modes < 1 || n_modes > 52 || (2 * n_valid) % 4 != 0 || 2 * n_valid > 640) return 0;   // stage C register blocking
     const StepLds L = step_lds_layout(n_act, n_subap, n_valid, n_modes);
     return (size_t)L.total * 4 <= 160 * 1024 - 1024 ? 1 : 0;     // static __shared__ of the kernel: < 1 KB
 }

@@ -31,3 +31,12 @@ print("total ticks", tot, " min/max", (st[:, 18] - st[:, 0]).min(), (st[:, 18] -
 t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
 t0.record(); env.run_integrator(50, 200); t1.record(); torch.cuda.synchronize()
 print("us/step", 1e3 * t0.elapsed_time(t1) / 200)
+
+ws = np.zeros((256, 16, 8), dtype=np.uint64)
+if hasattr(lib, "aoenv_debug_wstamps") and lib.aoenv_debug_wstamps(ws.ctypes.data_as(C.c_void_p)) == 0:
+    ws = ws.astype(np.int64)
+    t0 = ws[:, :, 0].min(axis=1, keepdims=True)
+    lab = ["wave start", "at s1 barrier", "after s1 barrier", "stage A done", "after E0 barrier", "spots done (at max barrier)", "end"]
+    print("per-wave timeline (ticks since the workgroup's first wave started), median over envs; waves 0..15")
+    for i, l in enumerate(lab):
+        print(f"{l:30s}", " ".join(f"{int(v):6d}" for v in np.median(ws[:N, :, i] - t0[:N], axis=0)))
