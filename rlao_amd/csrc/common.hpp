@@ -197,6 +197,8 @@ struct FftPlan {
     int n;            // transform length
     int n_fac;        // number of stages
     int fac[12];      // radix of each stage, product = n
+    unsigned magic_ns[12];   // floor(2^32 / ns) + 1 of each stage (ns = product of the earlier radices): x / ns for x < 2^16
+    unsigned magic_m[12];    // the same for m = n / radix
 };
 int make_fft_plan(int n, FftPlan* pl);
 template <typename T>

@@ -86,7 +86,7 @@ __device__ inline float gaussian(PixelRng& g) {
 }
 
 // photons in -> camera counts out
-__device__ inline float detector_pixel(float photons, const DetectorCfg& d, uint32_t pixel, uint32_t env) {
+__device__ __attribute__((noinline)) float detector_pixel(float photons, const DetectorCfg& d, uint32_t pixel, uint32_t env) {
     PixelRng g(pixel, env + d.env_offset, d.frame_counter, d.seed_lo, d.seed_hi);
     float f = photons;
     if (d.photon_noise) f = poisson(f, g);

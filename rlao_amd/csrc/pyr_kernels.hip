@@ -26,6 +26,8 @@ __global__ void __launch_bounds__(256) k_pyr_rows(const PyrArgs<T> a) {
     const int N = a.N, R = a.R, RB = a.seq_per_block;
     cx<T>* A = reinterpret_cast<cx<T>*>(lds_raw);
     cx<T>* B = A + RB * N;
+    cx<T>* twl = B + RB * N;
+    fft_load_twiddles<T>(twl, a.tw, N);
     const int e = blockIdx.z, th = blockIdx.y, y0 = blockIdx.x * RB;
     const int nrow = min(RB, R - y0);
     const T* ph = a.phase + (size_t)e * R * R;
@@ -51,7 +53,7 @@ __global__ void __launch_bounds__(256) k_pyr_rows(const PyrArgs<T> a) {
         }
         A[i] = v;
     }
-    cx<T>* out = fft_lds<T>(A, B, a.plan, RB, a.tw, 0);
+    cx<T>* out = fft_lds<T>(A, B, a.plan, RB, twl, 0);
     cx<T>* t1 = a.t1 + (((size_t)e * a.n_theta_chunk + th) * R + y0) * N;
     for (int i = threadIdx.x; i < nrow * N; i += blockDim.x) t1[i] = out[i];
 }
@@ -63,6 +65,8 @@ __global__ void __launch_bounds__(256) k_pyr_cols(const PyrArgs<T> a) {
     const int N = a.N, R = a.R, CB = a.seq_per_block;
     cx<T>* A = reinterpret_cast<cx<T>*>(lds_raw);
     cx<T>* B = A + CB * N;
+    cx<T>* twl = B + CB * N;
+    fft_load_twiddles<T>(twl, a.tw, N);
     const int e = blockIdx.z, th = blockIdx.y, kx0 = blockIdx.x * CB;
     const cx<T>* t1 = a.t1 + ((size_t)e * a.n_theta_chunk + th) * R * N;
     // gather: sequence c = column kx0 + c, element y (zero outside the pupil rows)
@@ -72,7 +76,7 @@ __global__ void __launch_bounds__(256) k_pyr_cols(const PyrArgs<T> a) {
         const int y = i / CB, c = i - y * CB;                     // lanes along the columns: contiguous in T1
         A[c * N + a.off + y] = t1[(size_t)y * N + kx0 + c];
     }
-    cx<T>* f = fft_lds<T>(A, B, a.plan, CB, a.tw, 0);
+    cx<T>* f = fft_lds<T>(A, B, a.plan, CB, twl, 0);
     cx<T>* g = (f == A) ? B : A;
     // focal plane: [fftshift] + mask   (Pyramid.py:486-497).  Shifted position i holds frequency (i + N/2) mod N.
     const int h = a.centering ? 0 : N / 2;
@@ -83,7 +87,7 @@ __global__ void __launch_bounds__(256) k_pyr_cols(const PyrArgs<T> a) {
         const T* mk = a.mask + 2 * ((size_t)ky * N + jx);
         g[i] = cmul(v, cx<T>{mk[0], mk[1]});
     }
-    cx<T>* r = fft_lds<T>(g, f, a.plan, CB, a.tw, 1);
+    cx<T>* r = fft_lds<T>(g, f, a.plan, CB, twl, 1);
     cx<T>* t2 = a.t2 + ((size_t)e * a.n_theta_chunk + th) * N * N;
     const int jx0 = (kx0 + h) % N;                                // CB divides N/2: the block's columns stay contiguous
     for (int i = threadIdx.x; i < N * CB; i += blockDim.x) {
@@ -99,7 +103,9 @@ __global__ void __launch_bounds__(256) k_pyr_rows_inv(const PyrArgs<T> a, int ac
     const int N = a.N, nb = N / a.cam;
     cx<T>* A = reinterpret_cast<cx<T>*>(lds_raw);
     cx<T>* B = A + nb * N;
-    T* acc = reinterpret_cast<T*>(B + nb * N);                    // [N] column sums of |.|^2 over the nb rows and the chunk
+    cx<T>* twl = B + nb * N;
+    T* acc = reinterpret_cast<T*>(twl + N);                       // [N] column sums of |.|^2 over the nb rows and the chunk
+    fft_load_twiddles<T>(twl, a.tw, N);
     const int e = blockIdx.y, cr = blockIdx.x;
     for (int i = threadIdx.x; i < N; i += blockDim.x) acc[i] = (T)0;
     const T scale = (T)1 / ((T)N * (T)N * (T)N * (T)N);            // ifft2 normalisation 1/N^2 on the amplitude
@@ -107,7 +113,7 @@ __global__ void __launch_bounds__(256) k_pyr_rows_inv(const PyrArgs<T> a, int ac
         const cx<T>* t2 = a.t2 + (((size_t)e * a.n_theta_chunk + th) * N + (size_t)cr * nb) * N;
         __syncthreads();
         for (int i = threadIdx.x; i < nb * N; i += blockDim.x) A[i] = t2[i];
-        cx<T>* r = fft_lds<T>(A, B, a.plan, nb, a.tw, 1);
+        cx<T>* r = fft_lds<T>(A, B, a.plan, nb, twl, 1);
         for (int x = threadIdx.x; x < N; x += blockDim.x) {
             T s = 0;
             for (int q = 0; q < nb; ++q) {
@@ -172,7 +178,12 @@ int launch_pyramid(const PyrArgs<T>& base, int n_theta, int chunk, hipStream_t s
     int cb = rb;
     while (cb > 1 && (N / 2) % cb) --cb;                          // CB must divide N/2 (fftshift keeps a block's columns contiguous)
     const int nb = N / a.cam;
-    const size_t lds3 = (size_t)(2 * nb * N) * sizeof(cx<T>) + (size_t)N * sizeof(T);
+    const size_t lds3 = (size_t)(2 * nb * N + N) * sizeof(cx<T>) + (size_t)N * sizeof(T);
+    const size_t lds1 = (size_t)(2 * rb * N + N) * sizeof(cx<T>), lds2 = (size_t)(2 * cb * N + N) * sizeof(cx<T>);
+    if (lds1 > 64 * 1024)
+        AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyr_rows<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+    if (lds2 > 64 * 1024)
+        AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyr_cols<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     if (lds3 > 160 * 1024) return fail("pyramid: %d rows of nRes = %d per camera row do not fit in LDS", nb, N);
     if (lds3 > 64 * 1024)
         AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyr_rows_inv<T>),
@@ -181,11 +192,9 @@ int launch_pyramid(const PyrArgs<T>& base, int n_theta, int chunk, hipStream_t s
         a.theta0 = t0;
         a.n_theta_chunk = (n_theta - t0) < chunk ? (n_theta - t0) : chunk;
         a.seq_per_block = rb;
-        hipLaunchKernelGGL(k_pyr_rows<T>, dim3(cdiv(R, rb), a.n_theta_chunk, a.n_env), dim3(256),
-                           2 * (size_t)rb * N * sizeof(cx<T>), st, a);
+        hipLaunchKernelGGL(k_pyr_rows<T>, dim3(cdiv(R, rb), a.n_theta_chunk, a.n_env), dim3(256), lds1, st, a);
         a.seq_per_block = cb;
-        hipLaunchKernelGGL(k_pyr_cols<T>, dim3(N / cb, a.n_theta_chunk, a.n_env), dim3(256),
-                           2 * (size_t)cb * N * sizeof(cx<T>), st, a);
+        hipLaunchKernelGGL(k_pyr_cols<T>, dim3(N / cb, a.n_theta_chunk, a.n_env), dim3(256), lds2, st, a);
         hipLaunchKernelGGL(k_pyr_rows_inv<T>, dim3(a.cam, a.n_env), dim3(256), lds3, st, a, t0 > 0 ? 1 : 0);
         AO_HIP(hipGetLastError());
     }
@@ -217,7 +226,12 @@ int make_fft_plan(int n, FftPlan* pl) {
     for (int p = 7; m > 1; p += 2)
         while (m % p == 0) { push(p); m /= p; }
     int prod = 1;
-    for (int i = 0; i < pl->n_fac; ++i) prod *= pl->fac[i];
+    for (int i = 0; i < pl->n_fac; ++i) {
+        pl->magic_ns[i] = (unsigned)((1ull << 32) / (unsigned)prod) + 1u;
+        pl->magic_m[i] = (unsigned)((1ull << 32) / (unsigned)(n / pl->fac[i])) + 1u;
+        prod *= pl->fac[i];
+    }
+    if (n > 8192) return fail("FFT length %d too long for the 16-bit index arithmetic", n);
     return prod == n ? 0 : fail("cannot factor the FFT length %d into at most 12 stages", n);
 }
 

@@ -19,6 +19,8 @@ __global__ void __launch_bounds__(256) k_screen_rows(const ScreenArgs a) {
     const int N = a.N, RB = a.seq_per_block, h = N / 2;
     cx<double>* A = reinterpret_cast<cx<double>*>(lds_raw);
     cx<double>* B = A + RB * N;
+    cx<double>* twl = B + RB * N;
+    fft_load_twiddles<double>(twl, a.tw, N);
     const int e = blockIdx.y, y0 = blockIdx.x * RB;
     const int nrow = min(RB, N - y0);
     const double* re = a.nrm + (size_t)e * 2 * N * N;
@@ -34,7 +36,7 @@ __global__ void __launch_bounds__(256) k_screen_rows(const ScreenArgs a) {
         }
         A[i] = v;
     }
-    cx<double>* out = fft_lds<double>(A, B, a.plan, RB, a.tw, 0);
+    cx<double>* out = fft_lds<double>(A, B, a.plan, RB, twl, 0);
     cx<double>* dst = a.scratch + ((size_t)e * N + y0) * N;
     for (int i = threadIdx.x; i < nrow * N; i += blockDim.x) dst[i] = out[i];
 }
@@ -45,6 +47,8 @@ __global__ void __launch_bounds__(256) k_screen_cols(const ScreenArgs a) {
     const int N = a.N, CB = a.seq_per_block, h = N / 2;
     cx<double>* A = reinterpret_cast<cx<double>*>(lds_raw);
     cx<double>* B = A + CB * N;
+    cx<double>* twl = B + CB * N;
+    fft_load_twiddles<double>(twl, a.tw, N);
     const int e = blockIdx.y, x0 = blockIdx.x * CB;
     const int ncol = min(CB, N - x0);
     const cx<double>* src = a.scratch + (size_t)e * N * N;
@@ -52,7 +56,7 @@ __global__ void __launch_bounds__(256) k_screen_cols(const ScreenArgs a) {
         const int y = i / CB, c = i - y * CB;
         A[c * N + y] = c < ncol ? src[(size_t)y * N + x0 + c] : cx<double>{0, 0};
     }
-    cx<double>* out = fft_lds<double>(A, B, a.plan, CB, a.tw, 0);
+    cx<double>* out = fft_lds<double>(A, B, a.plan, CB, twl, 0);
     double* hi = a.hi + (size_t)e * N * N;
     for (int i = threadIdx.x; i < N * CB; i += blockDim.x) {
         const int y = i / CB, c = i - y * CB;
@@ -120,7 +124,11 @@ int launch_screen(const ScreenArgs& base, T* map, int S, hipStream_t st) {
     if (rb < 1) return fail("screen generator: N = %d does not fit two LDS row buffers", N);
     rb = rb > 8 ? 8 : rb;
     a.seq_per_block = rb;
-    const size_t lds = 2 * (size_t)rb * N * sizeof(cx<double>);
+    const size_t lds = (2 * (size_t)rb * N + N) * sizeof(cx<double>);
+    if (lds > 64 * 1024) {
+        AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_screen_rows), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_screen_cols), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
     hipLaunchKernelGGL(k_screen_rows, dim3(cdiv(N, rb), a.n_env), dim3(256), lds, st, a);
     hipLaunchKernelGGL(k_screen_cols, dim3(cdiv(N, rb), a.n_env), dim3(256), lds, st, a);
     hipLaunchKernelGGL(k_screen_finish<T>, dim3(a.n_env), dim3(1024), 0, st, a, map, S);

@@ -242,3 +242,32 @@ def test_device_phase_screens_match_oracle(dtype, n_layer):
     env.measure()
     np.testing.assert_allclose(env.reset_soft().cpu().numpy(), obs_dev, atol=1e-6 if dtype == "f64" else 3e-5)
     env.close()
+
+
+@pytest.mark.parametrize("n_sub", [3, 7, 9])
+def test_pyramid_prime_radix_fft_matches_oracle(n_sub):
+    """Pyramid sizes whose padded FFT length nRes = 6 (2 nSub + 8) has a prime factor 7 / 11 / 13 (the BASELINE 40x40
+    Pyramid has nRes = 528 = 16.3.11): the register-resident prime-radix stage against the oracle's NumPy FFT path,
+    float64 shard, both mask centrings, with and without modulation."""
+    from oracle import ao_oracle as O                       # checker only
+    from rlao_amd import _lib as L
+    from rlao_amd.env import BatchedAOEnv
+    D = 0.4 * n_sub
+    geo = dict(diameter=D, nSubaperture=n_sub, nPixelPerSubap=6, r0=0.13, L0=30.0, windSpeed=[10.0], windDirection=[72.0],
+               fractionalR0=[1.0], altitude=[0.0], nModes=4, nLoop=16)
+    for centering, mod in ((True, 0.0), (False, 2.0)):
+        env = BatchedAOEnv(n_envs=2, device=0, dtype="f64")
+        env.set_params(dict(geo, psfCentering=centering, modulation=mod), wfs_type="pyramid")
+        ref = O.OracleEnv(resolution=6 * n_sub, diameter=D, n_subap=n_sub, r0=0.13, L0=30.0, windSpeed=[10.0],
+                          windDirection=[72.0], fractionalR0=[1.0], altitude=[0.0], m2c=env.M2C_CL, n_modes=4,
+                          wfs_type="pyramid", modulation=mod, psf_centering=centering)
+        assert env._pyr_tables.nRes % {3: 7, 7: 11, 9: 13}[n_sub] == 0
+        env.generate_new_phase_screen(5)
+        env.dm.coefs = 0
+        env.measure()
+        ref.new_episode(5)
+        frame = env._shard.download(L.B_FRAME, (2, env.cam_res, env.cam_res))[0]
+        sig = env._shard.download(L.B_SIGNAL, (2, env.nSignal))[0]
+        np.testing.assert_allclose(frame, ref.wfs.frame, rtol=0, atol=1e-9 * ref.wfs.frame.max())
+        np.testing.assert_allclose(sig, ref.wfs.signal, rtol=0, atol=1e-8)
+        env.close()
