@@ -28,7 +28,7 @@ GEOMETRY = dict(diameter=8.0, nSubaperture=20, nPixelPerSubap=6, r0=0.13, L0=30.
                 windDirection=[72.0], fractionalR0=[1.0], altitude=[0.0], magnitude=8.0, opticalBand="I",
                 mechanicalCoupling=0.35, nModes=50, gainCL=0.5, leak=0.99)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-PMC_TRAFFIC = os.path.join(REPO, "profiles", "r01_c_pmc_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+PMC_TRAFFIC = os.path.join(REPO, "profiles", "r01_d_pmc_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
 
 
 def measured_traffic(kernel, n_envs):
@@ -91,6 +91,9 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=256)
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--noise", action="store_true",
+                    help="WFS camera of the reference's Razor env (photon + dark + read-out noise, QE, FWC, 10-bit ADC: "
+                         "MAIN/OOPAOEnv/OOPAOEnvRazor.py:243-250, 333) instead of the ideal detector of the parity configuration")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     args = ap.parse_args()
 
@@ -111,6 +114,10 @@ def main():
     env = BatchedAOEnv(n_envs=n_local, device=local, dtype=args.dtype, return_frame=True,
                        env_index_offset=rank * n_local)
     env.set_params(dict(GEOMETRY, nLoop=2 * (K + W) + 16), wfs_type="shackhartmann")
+    if args.noise:
+        cam = env.wfs.cam
+        cam.sensor, cam.FWC, cam.bits, cam.QE, cam.darkCurrent, cam.integrationTime = "CMOS", 10000, 10, 0.56, 5, 1 / 500
+        cam.photonNoise, cam.readoutNoise = True, 14
     env.generate_new_phase_screen(17)              # env e of the job uses seed 17 + e
     env.dm.coefs = 0
     env.measure()
@@ -159,7 +166,7 @@ def main():
                                "(BASELINE.json configs[1])",
                    "envs_per_gpu": n_local, "envs_total": n_total, "resolution": env.R, "n_valid_act": env.nValidAct,
                    "n_signal": env.nSignal, "layers": env.param.nLayer, "controller": "leaky integrator, gain 0.5",
-                   "noise": "off", "parallelism": f"env-shards x{world}, all-gather of episode returns"},
+                   "noise": "Razor camera: photon + dark + read-out noise, QE 0.56, FWC 1e4, 10-bit ADC" if args.noise else "off", "parallelism": f"env-shards x{world}, all-gather of episode returns"},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(dom, n_local),
                      "algorithmic_bytes_per_launch": kbytes[dom] * n_local, "avg_launch_us": per_kernel[dom]["avg_us"]},

@@ -7,7 +7,7 @@
 //   read-out noise  + round(N(0,1) * sigma)           :218-221
 //   ADC  trunc(frame / FWC * (2^bits - 1)), clipped to 2^bits - 1   :190-201
 // The reference seeds its generators from the wall clock (Detector.py:127-130): a noisy frame is reproducible only in
-// distribution.  Here every pixel draws from a counter-based Philox4x32-10 stream keyed by (seed) and indexed by
+// distribution.  Here every pixel draws from a counter-based Philox4x32-7 stream keyed by (seed) and indexed by
 // (pixel, global env index, frame counter): reproducible, independent of the batch layout and of the kernel variant.
 #pragma once
 #include "common.hpp"
@@ -29,27 +29,50 @@ struct Philox {
 __device__ inline void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
     Philox p{{c0, c1, c2, c3}, {k0, k1}};
 #pragma unroll
-    for (int i = 0; i < 10; ++i) p.round();
+    for (int i = 0; i < 7; ++i) p.round();                       // Philox4x32-7 (Salmon et al. 2011: 7 rounds pass BigCrush):
+                                                                 // 32-bit integer multiplies are quarter-rate on CDNA
     out[0] = p.c[0]; out[1] = p.c[1]; out[2] = p.c[2]; out[3] = p.c[3];
 }
 
 __device__ inline float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }   // (0, 1)
 
-// One pixel's stream: uniforms on demand, 4 per Philox call.
+// One pixel's stream: uniforms on demand, 4 per Philox call (a shift register: no dynamically indexed array, which
+// the compiler would place in scratch memory).
 struct PixelRng {
     uint32_t c0, c1, c2, k0, k1, sub;
-    uint32_t buf[4];
+    uint32_t b0, b1, b2, b3;
     int have;
     __device__ inline PixelRng(uint32_t pixel, uint32_t env, uint32_t frame, uint32_t s0, uint32_t s1)
-        : c0(pixel), c1(env), c2(frame), k0(s0), k1(s1), sub(0), have(0) {}
+        : c0(pixel), c1(env), c2(frame), k0(s0), k1(s1), sub(0), b0(0), b1(0), b2(0), b3(0), have(0) {}
     __device__ inline float next() {
         if (have == 0) {
-            philox4x32(c0, c1, c2, sub++, k0, k1, buf);
+            uint32_t o[4];
+            philox4x32(c0, c1, c2, sub++, k0, k1, o);
+            b0 = o[3]; b1 = o[2]; b2 = o[1]; b3 = o[0];        // handed out in the order o[3], o[2], o[1], o[0]
             have = 4;
         }
-        return u01(buf[--have]);
+        const uint32_t v = b0;
+        b0 = b1; b1 = b2; b2 = b3;
+        --have;
+        return u01(v);
     }
 };
+
+// log(k!) for integer-valued k >= 0: table below 16, Stirling's series (two correction terms, |error| < 2e-9) above.
+// (lgammaf costs ~10x more instructions, and the PTRS acceptance test below runs for every lit pixel of every frame.)
+__device__ inline float log_factorial(float k) {
+    if (k < 16.f) {
+        const float tab[16] = {0.f, 0.f, 0.693147181f, 1.791759469f, 3.17805383f, 4.787491743f, 6.579251212f, 8.525161361f,
+                               10.604602903f, 12.801827480f, 15.104412573f, 17.502307846f, 19.987214496f, 22.552163853f,
+                               25.191221183f, 27.899271384f};
+        float v = 0.f;
+#pragma unroll
+        for (int i = 2; i < 16; ++i) v = (k == (float)i) ? tab[i] : v;
+        return v;
+    }
+    const float r = 1.f / k;
+    return k * __logf(k) - k + 0.5f * __logf(6.283185307179586f * k) + r * (0.0833333333f - 0.00277777778f * r * r);
+}
 
 // Poisson(lam): sequential inversion below 12 (exact, ~lam iterations), Hoermann's PTRS above (exact; the algorithm
 // NumPy's legacy generator uses for lam >= 10).
@@ -75,7 +98,7 @@ __device__ inline float poisson(float lam, PixelRng& g) {
         const float kf = floorf((2.f * a / us + b) * U + lam + 0.43f);
         if (us >= 0.07f && V <= vr) return kf;
         if (kf < 0.f || (us < 0.013f && V > us)) continue;
-        if (__logf(V) + __logf(invalpha) - __logf(a / (us * us) + b) <= -lam + kf * loglam - lgammaf(kf + 1.f)) return kf;
+        if (__logf(V) + __logf(invalpha) - __logf(a / (us * us) + b) <= -lam + kf * loglam - log_factorial(kf)) return kf;
     }
     return floorf(lam + 0.5f);
 }
@@ -86,7 +109,7 @@ __device__ inline float gaussian(PixelRng& g) {
 }
 
 // photons in -> camera counts out
-__device__ __attribute__((noinline)) float detector_pixel(float photons, const DetectorCfg& d, uint32_t pixel, uint32_t env) {
+__device__ inline float detector_pixel(float photons, const DetectorCfg& d, uint32_t pixel, uint32_t env) {
     PixelRng g(pixel, env + d.env_offset, d.frame_counter, d.seed_lo, d.seed_hi);
     float f = photons;
     if (d.photon_noise) f = poisson(f, g);
