@@ -99,7 +99,7 @@ enum AoConst {
  * environment state of SURVEY.md section 5 "checkpoint / resume" plus the stage boundaries the parity
  * tests compare.  Shapes are per shard, leading dimension n_env unless noted. */
 enum AoBuf {
-    AOENV_B_SCREEN = 0,      /* [n_layer][n_env][(N+2)^2]  layer.mapShift                                */
+    AOENV_B_SCREEN = 0,      /* [n_layer][n_env][(N+2)^2]  layer.mapShift (download only: stored as a torus)   */
     AOENV_B_OPD_ATM,         /* [n_env][R*R]   atm.OPD_no_pupil                                          */
     AOENV_B_COEFS,           /* [n_env][A]     dm.coefs                                                  */
     AOENV_B_PHASE,           /* [n_env][R*R]   tel.src.phase (residual, pupil-masked, rad @ src)          */

@@ -39,18 +39,17 @@ struct AoEnv {
     int R = 0, N = 0, S = 0, A = 0, nAct = 0, E = 0, L = 0, nin = 0, nout = 0, K = 0, nSig = 0, nSub = 0, nVal = 0;
     int p = 0, n = 0, n_pupil = 0;
     LayerClock clk[kMaxLayer];
-    int cur[kMaxLayer] = {0};                // (always 0: the screens are tori, nothing is copied on a shift)
     int org[kMaxLayer][2] = {{0, 0}};        // torus origin (oy, ox) of every layer: logical (r, c) at ((r + oy) % S, (c + ox) % S)
     bool minmax_dirty[kMaxLayer] = {false};  // the layer's min / max table is stale (ring extruded without the min / max pass)
     bool have[AOENV_C_COUNT] = {false};
     double units = 1.0;
     // device memory (element type = dtype unless noted)
-    void* screen[2] = {nullptr, nullptr};   // [0]: [L][E][S*S] tori ([1] unused)
+    void* screen[1] = {nullptr};            // [L][E][S*S], every screen a torus (see atm_kernels.hip)
     void* minmax = nullptr;                 // [L][E][2]
     uint32_t* mt_state = nullptr;           // [L][E][624]
     int* mt_pos = nullptr;                  // [L][E]
     void* zx = nullptr;                     // [E][K]  [Z | xi]
-    void* xbuf = nullptr;                   // [E][nout]
+    void* xbuf = nullptr;                   // [splits][E][nout] split-K slabs of the ring GEMM
     void* ab = nullptr;                     // [nout][K]
     int* inner_idx = nullptr;
     int* outer_idx = nullptr;
@@ -99,7 +98,6 @@ struct AoEnv {
     FftPlan pyr_plan{};
     int pyr_chunk = 1;
     void* vbuf = nullptr;                   // [E][A]
-    void* obs_scratch = nullptr;            // [E][nAct*nAct]
     DetectorCfg det{};                      // aoenv_set_detector(); det.active = 0: ideal camera
     void* ret_acc = nullptr;                // caller-owned [E] episode-return accumulator (aoenv_set_return_accumulator)
     std::vector<void*> allocs;
@@ -686,7 +684,6 @@ int aoenv_create(const AoCfg* cfg, int device, AoEnv** out) {
         A_(&e->pyr_t2, E * e->pyr_chunk * N * N * 2 * z);
     }
     A_(&e->vbuf, (size_t)kMaxSplits * E * e->A * z);
-    A_(&e->obs_scratch, E * (size_t)e->nAct * e->nAct * z);
     if (rc) { aoenv_destroy(e); return rc; }
 
     // DFT twiddles w^k = exp(-2 pi i k / n) and the centring phasor exp(-i pi (n+1)/n x) at x = a + lo
@@ -1147,7 +1144,7 @@ int aoenv_buffer(AoEnv* env, int which, void** d_ptr, size_t* bytes) {
     AO_CHECK_ENV(env);
     BufInfo b{};
     AO_TRY(buf_info(env, which, &b));
-    if (which == AOENV_B_SCREEN) return fail("the screens are a ping-pong pair: use aoenv_download / aoenv_upload_state");
+    if (which == AOENV_B_SCREEN) return fail("the screens are stored as tori (moving origin): use aoenv_download, which returns the logical layer.mapShift");
     if (d_ptr) *d_ptr = b.ptr;
     if (bytes) *bytes = b.bytes;
     return 0;
