@@ -228,6 +228,8 @@ enum AoOption {
     AOENV_OPT_FUSED_STEP = 5, /* 1 (default): float32 SH shards with 6 px per lenslet, <= 336 valid lenslets, R <= 128 and uploaded
                                  AOENV_C_RECON_FACTORS run the whole step as ONE kernel, one workgroup per env, every intermediate in LDS;
                                  0: the separate phase / spots / tail kernels */
+    AOENV_OPT_DEFER_RING = 6, /* 1 (default): on a step where a layer crosses a pixel, the fused step kernel itself writes the new
+                                 border ring of the screen (sum of the ring GEMM's slabs); 0: a separate scatter launch */
     AOENV_OPT_FAST_TRIG = 2  /* 1 (default): v_sin/v_cos after Cody-Waite reduction in the float32 SH kernel; 0: sincosf */
 };
 int aoenv_set_option(AoEnv* env, int option, int value);

@@ -19,7 +19,7 @@ WFS_SH, WFS_PYRAMID = 0, 1
 (B_SCREEN, B_OPD_ATM, B_COEFS, B_PHASE, B_FRAME, B_SIGNAL, B_TOTAL, B_RESIDUAL, B_WFS_MAX, B_XI) = range(10)
 
 
-OPT_FAST_WFS, OPT_MFMA_GEMM, OPT_FAST_TRIG, OPT_STORE_ATM_OPD, OPT_FUSED_TAIL, OPT_FUSED_STEP = 0, 1, 2, 3, 4, 5
+OPT_FAST_WFS, OPT_MFMA_GEMM, OPT_FAST_TRIG, OPT_STORE_ATM_OPD, OPT_FUSED_TAIL, OPT_FUSED_STEP, OPT_DEFER_RING = 0, 1, 2, 3, 4, 5, 6
 KERNEL_NAMES = ("ring_prepare", "mt_normal", "gemm_ring", "ring_scatter", "phase", "sh_spots", "sh_centroid",
                 "gemm_recon", "recon_finish", "pyramid", "sh_tail", "env_step")
 

@@ -183,6 +183,11 @@ struct StepArgs {
     const float* gxa;            // [128][4][8] gx[x][q + 4 s] at [x][q][s], zero padded: MFMA operands as two 16-byte loads
     const float* gya;            // [128][4][8] gy[y][q + 4 s]
     DetectorCfg det;             // WFS camera (active = 0: ideal)
+    // ring extrusion whose scatter was deferred to this kernel (add_row part 3, OOPAO/Atmosphere.py:309-310):
+    const float* ring_x[kMaxLayer];   // [splits][E][n_outer] split-K slabs of X = A Z + B xi of the layer, null = nothing pending
+    int ring_splits[kMaxLayer];
+    const int* outer_idx;        // [n_outer] logical flat index of every ring pixel
+    int n_outer;
     int n_modes, n_subap, n_valid, n_env;
 };
 int step_fused_supported(int R, int n_subap, int n_valid, int n_act, int n_modes);

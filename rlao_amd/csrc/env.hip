@@ -40,6 +40,8 @@ struct AoEnv {
     int p = 0, n = 0, n_pupil = 0;
     LayerClock clk[kMaxLayer];
     int org[kMaxLayer][2] = {{0, 0}};        // torus origin (oy, ox) of every layer: logical (r, c) at ((r + oy) % S, (c + ox) % S)
+    int ring_pending[kMaxLayer] = {0};       // > 0: split count of a ring extrusion whose scatter the next fused step kernel will do
+    bool defer_ring = true;                  // aoenv_set_option(AOENV_OPT_DEFER_RING)
     bool minmax_dirty[kMaxLayer] = {false};  // the layer's min / max table is stale (ring extruded without the min / max pass)
     bool have[AOENV_C_COUNT] = {false};
     double units = 1.0;
@@ -119,6 +121,7 @@ struct AoEnv {
         return static_cast<char*>(screen[which]) + (size_t)l * E * S * S * esz;
     }
     void* minmax_ptr(int l) const { return static_cast<char*>(minmax) + (size_t)l * E * 2 * esz; }
+    void* xbuf_ptr(int l) const { return static_cast<char*>(xbuf) + (size_t)l * kMaxSplits * E * nout * esz; }
 };
 
 namespace {
@@ -212,7 +215,26 @@ int gemm_dispatch<double>(AoEnv*, const double* X, const double* W, double* C, i
 // ---- add_row on the device (OOPAO/Atmosphere.py:301-311) for every env of the shard ---------------
 // lean = true: the ring is scattered without the min / max pass; the fused step kernel recomputes the range from the map
 template <typename T>
-int extrude(AoEnv* env, int l, int sx, int sy, bool lean, hipStream_t st) {
+int flush_ring(AoEnv* env, int l, hipStream_t st) {
+    if (!env->ring_pending[l]) return 0;
+    AO_PROF(env, SCATTER, st);
+    AO_TRY(launch_scatter_minmax<T>(env->as<T>(env->screen_ptr(0, l)), env->as<T>(env->xbuf_ptr(l)), env->outer_idx,
+                                    env->as<T>(env->minmax_ptr(l)), env->E, env->S, env->nout, env->ring_pending[l],
+                                    env->org[l][0], env->org[l][1], 0, st));
+    env->ring_pending[l] = 0;
+    return 0;
+}
+template <typename T>
+int flush_rings(AoEnv* env, hipStream_t st) {
+    for (int l = 0; l < env->L; ++l) AO_TRY(flush_ring<T>(env, l, st));
+    return 0;
+}
+
+// lean: no min / max pass (the fused step kernel recomputes the range from the map);  defer: not even the scatter -- the
+// fused step kernel of this step writes the ring itself (one launch less per crossing)
+template <typename T>
+int extrude(AoEnv* env, int l, int sx, int sy, bool lean, hipStream_t st, bool defer = false) {
+    AO_TRY(flush_ring<T>(env, l, st));                             // an earlier extrusion of this layer in the same step
     T* map = env->as<T>(env->screen_ptr(0, l));
     T* zx = env->as<T>(env->zx);
     const int S = env->S;
@@ -226,15 +248,17 @@ int extrude(AoEnv* env, int l, int sx, int sy, bool lean, hipStream_t st) {
     int splits = 1;
     {
         AO_PROF(env, GEMM_RING, st);
-        AO_TRY(gemm_dispatch<T>(env, zx, env->as<T>(env->ab), env->as<T>(env->xbuf), env->E, env->nout, env->K, &splits,
+        AO_TRY(gemm_dispatch<T>(env, zx, env->as<T>(env->ab), env->as<T>(env->xbuf_ptr(l)), env->E, env->nout, env->K, &splits,
                                 st));
     }
     // the shift itself: move the origin of the torus
     env->org[l][0] = ((oy - sy) % S + S) % S;
     env->org[l][1] = ((ox - sx) % S + S) % S;
-    {
+    if (defer && lean) {
+        env->ring_pending[l] = splits;
+    } else {
         AO_PROF(env, SCATTER, st);
-        AO_TRY(launch_scatter_minmax<T>(map, env->as<T>(env->xbuf), env->outer_idx, env->as<T>(env->minmax_ptr(l)), env->E, S,
+        AO_TRY(launch_scatter_minmax<T>(map, env->as<T>(env->xbuf_ptr(l)), env->outer_idx, env->as<T>(env->minmax_ptr(l)), env->E, S,
                                         env->nout, splits, env->org[l][0], env->org[l][1], lean ? 0 : 1, st));
     }
     env->minmax_dirty[l] = lean;
@@ -244,6 +268,7 @@ int extrude(AoEnv* env, int l, int sx, int sy, bool lean, hipStream_t st) {
 // make every layer's min / max table current (consumers other than the fused step kernel)
 template <typename T>
 int refresh_minmax(AoEnv* env, hipStream_t st) {
+    AO_TRY(flush_rings<T>(env, st));
     for (int l = 0; l < env->L; ++l)
         if (env->minmax_dirty[l]) {
             AO_TRY(launch_minmax<T>(env->as<T>(env->screen_ptr(0, l)), env->as<T>(env->minmax_ptr(l)), env->E, env->S, st));
@@ -268,7 +293,7 @@ int advance_atmosphere(AoEnv* env, bool lean, hipStream_t st) {
         if (std::fabs(k.buff[0]) >= 1 || std::fabs(k.buff[1]) >= 1) {
             const int b0 = std::fabs(k.buff[0]) < 1 ? 0 : (int)sgn(k.buff[0]);
             const int b1 = std::fabs(k.buff[1]) < 1 ? 0 : (int)sgn(k.buff[1]);
-            AO_TRY(extrude<T>(env, l, b0, b1, lean, st));
+            AO_TRY(extrude<T>(env, l, b0, b1, lean, st, lean && env->defer_ring));
         }
         for (int d = 0; d < 2; ++d) k.buff[d] = std::fmod(std::fabs(k.buff[d]), 1.0) * sgn(k.buff[d]);
     }
@@ -487,6 +512,12 @@ int run_fused_step<float>(AoEnv* env, int i, const void* d_action, void* d_obs, 
     a.gya = env->gya;
     if (env->det.active) env->det.frame_counter += 1;              // every measurement is a new frame of the noise streams
     a.det = env->det;
+    for (int l = 0; l < env->L; ++l) {
+        a.ring_x[l] = env->ring_pending[l] ? env->as<float>(env->xbuf_ptr(l)) : nullptr;
+        a.ring_splits[l] = env->ring_pending[l];
+    }
+    a.outer_idx = env->outer_idx;
+    a.n_outer = env->nout;
     a.n_modes = env->n_modes;
     a.n_subap = env->nSub;
     a.n_valid = env->nVal;
@@ -496,6 +527,7 @@ int run_fused_step<float>(AoEnv* env, int i, const void* d_action, void* d_obs, 
         AO_TRY(launch_env_step(a, st));
     }
     for (int l = 0; l < env->L; ++l) env->minmax_dirty[l] = false;   // the kernel recomputed and stored them
+    for (int l = 0; l < env->L; ++l) env->ring_pending[l] = 0;        // ... and wrote the deferred rings
     return 0;
 }
 
@@ -636,7 +668,7 @@ int aoenv_create(const AoCfg* cfg, int device, AoEnv** out) {
         A_((void**)&e->mt_state, (size_t)e->L * E * kMtN * 4);
         A_((void**)&e->mt_pos, (size_t)e->L * E * 4);
         A_(&e->zx, E * e->K * z);
-        A_(&e->xbuf, (size_t)kMaxSplits * E * e->nout * z);
+        A_(&e->xbuf, (size_t)e->L * kMaxSplits * E * e->nout * z);
         A_(&e->ab, (size_t)e->nout * e->K * z);
         A_((void**)&e->inner_idx, (size_t)e->nin * 4);
         A_((void**)&e->outer_idx, (size_t)e->nout * 4);
@@ -893,6 +925,7 @@ static int require_step_constants(AoEnv* env, bool atmosphere) {
 // after the new interior is in mapShift (OOPAO/Atmosphere.py:579-592)
 static int finish_new_screens(AoEnv* env, const uint32_t* h_ring_seeds, hipStream_t st) {
     const int E = env->E, L = env->L;
+    for (int l = 0; l < L; ++l) env->ring_pending[l] = 0;          // a deferred ring of the old screens is moot
     std::vector<uint32_t> keys((size_t)L * E * kMtN);
     std::vector<int> pos((size_t)L * E, kMtN);
     for (int l = 0; l < L; ++l)
@@ -1158,6 +1191,8 @@ int aoenv_download(AoEnv* env, int which, void* h_dst, size_t bytes, void* strea
     hipStream_t st = static_cast<hipStream_t>(stream);
     AO_HIP(hipStreamSynchronize(st));
     if (which == AOENV_B_SCREEN) {
+        AO_TRY(AO_DISPATCH(env, flush_rings, env, st));
+        AO_HIP(hipStreamSynchronize(st));
         // the device keeps every screen as a torus: hand back the logical layer.mapShift
         const int S = env->S;
         const size_t per = (size_t)env->E * S * S * env->esz, z = env->esz;
@@ -1223,6 +1258,7 @@ int aoenv_set_option(AoEnv* env, int option, int value) {
         case AOENV_OPT_STORE_ATM_OPD: env->store_opd_atm = value != 0; return 0;
         case AOENV_OPT_FUSED_TAIL: env->use_fused_tail = value != 0; return 0;
         case AOENV_OPT_FUSED_STEP: env->use_fused_step = value != 0; return 0;
+        case AOENV_OPT_DEFER_RING: env->defer_ring = value != 0; return 0;
         case 99: env->debug_ablate = value; return 0;
         default: return fail("unknown option %d", option);
     }

@@ -178,6 +178,38 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
         }
     }
 
+    // ---- deferred ring scatter: map_full[outerMask] = X of a layer that crossed a pixel this step ----------------------------
+    // The ring values are the fixed-order sum of the GEMM's split-K slabs, written through the torus origin.  This
+    // workgroup is the only reader of this env's map in this launch, and its vector L1 holds no line of it yet (no load of
+    // the map has been issued in this kernel): after the stores are acknowledged (vmcnt 0) and the barrier, the loads below
+    // read them back from L2.
+    {
+        bool any = false;
+        for (int l = 0; l < k.pa.n_layer; ++l) {
+            const float* x = a.ring_x[l];
+            if (x == nullptr) continue;
+            any = true;
+            float* map = const_cast<float*>(static_cast<const float*>(k.pa.screen[l])) + (size_t)e * S * S;
+            const size_t slab = (size_t)a.n_env * a.n_outer;
+            const int oy = k.pa.taps[l].oy, ox = k.pa.taps[l].ox;
+            for (int q = tid; q < a.n_outer; q += 1024) {
+                float xv[kMaxSplits];                             // all slabs in flight at once, summed in slab order
+#pragma unroll
+                for (int z = 0; z < kMaxSplits; ++z)
+                    xv[z] = x[(size_t)(z < a.ring_splits[l] ? z : 0) * slab + (size_t)e * a.n_outer + q];
+                float v = xv[0];
+#pragma unroll
+                for (int z = 1; z < kMaxSplits; ++z) v += z < a.ring_splits[l] ? xv[z] : 0.f;
+                const int idx = a.outer_idx[q];
+                int pr = idx / S + oy, pc = idx % S + ox;
+                pr = pr >= S ? pr - S : pr;
+                pc = pc >= S ? pc - S : pc;
+                map[pr * S + pc] = v;
+            }
+        }
+        if (any) __syncthreads();                                // s_waitcnt vmcnt(0) lgkmcnt(0) + barrier: stores acknowledged
+    }
+
     // ---- range of every layer's screen (the warp clips to it): read back, or recomputed here after a ring extrusion -------
     __shared__ float lohi[kMaxLayer][2];
     __shared__ float red_lo[16], red_hi[16];
