@@ -109,6 +109,9 @@ enum AoBuf {
     AOENV_B_RESIDUAL,        /* [n_loop][n_env] env.residual (nm rms)                                    */
     AOENV_B_WFS_MAX,         /* [n_env]        max of the valid spot intensities (threshold reference)   */
     AOENV_B_XI,              /* [n_env][n_inner+n_outer] last [Z | xi] operand of the ring extrusion      */
+    AOENV_B_MT_STATE,        /* [n_layer][n_env][625] uint32 (whatever the env dtype): the 624 MT19937 state words of
+                                the layer's ring RandomState and its position (OOPAO/Atmosphere.py:201, 308)         */
+    AOENV_B_COUNTERS,        /* [4] uint32: frame counter of the camera noise streams, 3 reserved                 */
     AOENV_B_COUNT
 };
 
@@ -207,8 +210,10 @@ int aoenv_set_detector(AoEnv* env, const AoDetector* cfg);
  * to it.  NULL detaches it.  The caller zeroes it at the start of an episode. */
 int aoenv_set_return_accumulator(AoEnv* env, void* d_return);
 
-/* State access (get_state / set_state; also the stage boundaries compared by the
- * parity tests).  `which` is an AoBuf.  aoenv_buffer returns the device pointer and size in bytes;
+/* State access (get_state / set_state = checkpoint / resume of the env; also the stage boundaries
+ * compared by the parity tests).  The complete loop state is {AOENV_B_SCREEN, aoenv_get_buff, AOENV_B_MT_STATE,
+ * AOENV_B_COEFS, AOENV_B_COUNTERS} plus the caller's last observation; aoenv_upload_state(AOENV_B_SCREEN) takes the
+ * logical layer.mapShift (as aoenv_download returns it) and re-derives the clip range.  `which` is an AoBuf.  aoenv_buffer returns the device pointer and size in bytes;
  * aoenv_download copies to a host buffer of the env dtype and synchronises the stream. */
 int aoenv_buffer(AoEnv* env, int which, void** d_ptr, size_t* bytes);
 int aoenv_download(AoEnv* env, int which, void* h_dst, size_t bytes, void* stream);

@@ -16,7 +16,8 @@ WFS_SH, WFS_PYRAMID = 0, 1
 (C_PUPIL, C_AB, C_INNER_IDX, C_OUTER_IDX, C_LAYER_WEIGHT, C_DM_GX, C_DM_GY, C_DM_MODES, C_ACT_IDX, C_WFS_AMP,
  C_SH_SUBAP_IDX, C_SH_REF, C_WFS_UNITS, C_RECON, C_PYR_MASK, C_PYR_TT, C_RECON_FACTORS) = range(17)
 # enum AoBuf
-(B_SCREEN, B_OPD_ATM, B_COEFS, B_PHASE, B_FRAME, B_SIGNAL, B_TOTAL, B_RESIDUAL, B_WFS_MAX, B_XI) = range(10)
+(B_SCREEN, B_OPD_ATM, B_COEFS, B_PHASE, B_FRAME, B_SIGNAL, B_TOTAL, B_RESIDUAL, B_WFS_MAX, B_XI, B_MT_STATE,
+ B_COUNTERS) = range(12)
 
 
 OPT_FAST_WFS, OPT_MFMA_GEMM, OPT_FAST_TRIG, OPT_STORE_ATM_OPD, OPT_FUSED_TAIL, OPT_FUSED_STEP, OPT_DEFER_RING = 0, 1, 2, 3, 4, 5, 6

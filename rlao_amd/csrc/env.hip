@@ -606,6 +606,8 @@ int buf_info(AoEnv* env, int which, BufInfo* b) {
         case AOENV_B_RESIDUAL: *b = {env->residual, (size_t)env->c.n_loop * E * z}; return 0;
         case AOENV_B_WFS_MAX: *b = {env->wfs_max, E * z}; return 0;
         case AOENV_B_XI: *b = {env->zx, E * env->K * z}; return 0;
+        case AOENV_B_MT_STATE: *b = {nullptr, (size_t)env->L * E * (kMtN + 1) * 4}; return 0;     // packed on the host
+        case AOENV_B_COUNTERS: *b = {nullptr, 16}; return 0;
         default: return fail("unknown buffer id %d", which);
     }
 }
@@ -1177,7 +1179,8 @@ int aoenv_buffer(AoEnv* env, int which, void** d_ptr, size_t* bytes) {
     AO_CHECK_ENV(env);
     BufInfo b{};
     AO_TRY(buf_info(env, which, &b));
-    if (which == AOENV_B_SCREEN) return fail("the screens are stored as tori (moving origin): use aoenv_download, which returns the logical layer.mapShift");
+    if (which == AOENV_B_SCREEN || which == AOENV_B_MT_STATE || which == AOENV_B_COUNTERS)
+        return fail("buffer %d has no flat device image (tori / host-side state): use aoenv_download / aoenv_upload_state", which);
     if (d_ptr) *d_ptr = b.ptr;
     if (bytes) *bytes = b.bytes;
     return 0;
@@ -1211,6 +1214,26 @@ int aoenv_download(AoEnv* env, int which, void* h_dst, size_t bytes, void* strea
         }
         return 0;
     }
+    if (which == AOENV_B_MT_STATE) {
+        const size_t n = (size_t)env->L * env->E;
+        std::vector<uint32_t> st_(n * kMtN);
+        std::vector<int> pos(n);
+        if (n) {
+            AO_HIP(hipMemcpy(st_.data(), env->mt_state, st_.size() * 4, hipMemcpyDeviceToHost));
+            AO_HIP(hipMemcpy(pos.data(), env->mt_pos, pos.size() * 4, hipMemcpyDeviceToHost));
+        }
+        uint32_t* out = static_cast<uint32_t*>(h_dst);
+        for (size_t i = 0; i < n; ++i) {
+            std::memcpy(out + i * (kMtN + 1), &st_[i * kMtN], kMtN * 4);
+            out[i * (kMtN + 1) + kMtN] = (uint32_t)pos[i];
+        }
+        return 0;
+    }
+    if (which == AOENV_B_COUNTERS) {
+        uint32_t* out = static_cast<uint32_t*>(h_dst);
+        out[0] = env->det.frame_counter; out[1] = out[2] = out[3] = 0;
+        return 0;
+    }
     if (which == AOENV_B_OPD_ATM && env->L > 0 && !env->atm_user_defined && !env->store_opd_atm) {
         // not written by the step kernels unless AOENV_OPT_STORE_ATM_OPD: re-derive it from the screens now
         // (same kernel, same sampling constants; the residual phase it rewrites is identical)
@@ -1228,7 +1251,38 @@ int aoenv_upload_state(AoEnv* env, int which, const void* h_src, size_t bytes, v
     if (bytes != b.bytes) return fail("aoenv_upload_state(%d): got %zu bytes, expected %zu", which, bytes, b.bytes);
     hipStream_t st = static_cast<hipStream_t>(stream);
     AO_HIP(hipStreamSynchronize(st));
-    if (which == AOENV_B_SCREEN) return fail("screen upload is not implemented (it also needs the min/max table)");
+    if (which == AOENV_B_SCREEN) {
+        // logical layer.mapShift of every env: the tori restart at origin 0; the clip range is re-derived by its next consumer
+        for (int l = 0; l < env->L; ++l) {
+            const size_t per = (size_t)env->E * env->S * env->S * env->esz;
+            AO_HIP(hipMemcpy(env->screen_ptr(0, l), static_cast<const char*>(h_src) + l * per, per, hipMemcpyHostToDevice));
+            env->org[l][0] = env->org[l][1] = 0;
+            env->ring_pending[l] = 0;
+            env->minmax_dirty[l] = true;
+        }
+        env->atm_user_defined = false;
+        return 0;
+    }
+    if (which == AOENV_B_MT_STATE) {
+        const size_t n = (size_t)env->L * env->E;
+        std::vector<uint32_t> st_(n * kMtN);
+        std::vector<int> pos(n);
+        const uint32_t* in = static_cast<const uint32_t*>(h_src);
+        for (size_t i = 0; i < n; ++i) {
+            std::memcpy(&st_[i * kMtN], in + i * (kMtN + 1), kMtN * 4);
+            pos[i] = (int)in[i * (kMtN + 1) + kMtN];
+            if (pos[i] < 0 || pos[i] > kMtN || pos[i] % 4) return fail("MT19937 position %d is not a multiple of 4 in [0, 624]", pos[i]);
+        }
+        if (n) {
+            AO_HIP(hipMemcpy(env->mt_state, st_.data(), st_.size() * 4, hipMemcpyHostToDevice));
+            AO_HIP(hipMemcpy(env->mt_pos, pos.data(), pos.size() * 4, hipMemcpyHostToDevice));
+        }
+        return 0;
+    }
+    if (which == AOENV_B_COUNTERS) {
+        env->det.frame_counter = static_cast<const uint32_t*>(h_src)[0];
+        return 0;
+    }
     AO_HIP(hipMemcpy(b.ptr, h_src, bytes, hipMemcpyHostToDevice));
     if (which == AOENV_B_COEFS) return AO_DISPATCH(env, refresh_dense_dm, env, st);
     return 0;

@@ -83,13 +83,13 @@ class Shard:
     def measure(self, stream=0):
         L.check(self.lib.aoenv_measure(self.h, C.c_void_p(stream)))
 
-    def download(self, which: int, shape, stream=0) -> np.ndarray:
-        out = np.empty(shape, dtype=self.np_dtype)
+    def download(self, which: int, shape, stream=0, dtype=None) -> np.ndarray:
+        out = np.empty(shape, dtype=self.np_dtype if dtype is None else dtype)
         L.check(self.lib.aoenv_download(self.h, which, out.ctypes.data_as(C.c_void_p), out.nbytes, C.c_void_p(stream)))
         return out
 
-    def upload_state(self, which: int, arr, stream=0):
-        a = np.ascontiguousarray(arr, dtype=self.np_dtype)
+    def upload_state(self, which: int, arr, stream=0, dtype=None):
+        a = np.ascontiguousarray(arr, dtype=self.np_dtype if dtype is None else dtype)
         L.check(self.lib.aoenv_upload_state(self.h, which, a.ctypes.data_as(C.c_void_p), a.nbytes, C.c_void_p(stream)))
 
     def profile(self, enable: bool):
@@ -667,6 +667,36 @@ class BatchedAOEnv:
             self._shard.h, int(i0), int(n_steps), g, C.c_void_p(self._obs.data_ptr()), None,
             C.c_void_p(self._reward.data_ptr()), C.c_void_p(self._strehl.data_ptr()), C.c_void_p(self._stream())))
         return self._obs, self._reward, self._strehl
+
+    # -- checkpoint / resume (env state = screens, sub-pixel accumulators, ring RNG, dm coefs) --------
+    def get_state(self) -> dict:
+        """Everything the next ``step`` depends on, as host arrays: restoring it with ``set_state`` (same geometry, same
+        n_envs) continues the episode bit for bit."""
+        sh, p, at = self._shard, self.param, self._atm_tables
+        st = self._stream()
+        return {
+            "screen": sh.download(L.B_SCREEN, (p.nLayer, self.n_envs, at.S, at.S), st),
+            "buff": sh.get_buff(p.nLayer).copy(),
+            "mt": sh.download(L.B_MT_STATE, (p.nLayer, self.n_envs, 625), st, dtype=np.uint32),
+            "coefs": sh.download(L.B_COEFS, (self.n_envs, self.nValidAct), st),
+            "signal": sh.download(L.B_SIGNAL, (self.n_envs, self.nSignal), st),
+            "counters": sh.download(L.B_COUNTERS, (4,), st, dtype=np.uint32),
+            "obs": self._obs.detach().cpu().numpy().copy(),
+            "windSpeed": list(p.windSpeed), "windDirection": list(p.windDirection),
+        }
+
+    def set_state(self, state: dict):
+        sh, p = self._shard, self.param
+        st = self._stream()
+        p.windSpeed, p.windDirection = list(state["windSpeed"]), list(state["windDirection"])
+        self._push_wind(reset=False)
+        sh.upload_state(L.B_SCREEN, state["screen"], st)
+        sh.set_buff(state["buff"])
+        sh.upload_state(L.B_MT_STATE, state["mt"], st, dtype=np.uint32)
+        sh.upload_state(L.B_COEFS, state["coefs"], st)
+        sh.upload_state(L.B_SIGNAL, state["signal"], st)
+        sh.upload_state(L.B_COUNTERS, state["counters"], st, dtype=np.uint32)
+        self._obs.copy_(_torch().as_tensor(state["obs"], device=self.device, dtype=self.tdtype))
 
     def accumulate_returns(self, tensor):
         """Attach a device tensor [n_envs] (env dtype) to which every step adds its reward (None detaches): the
