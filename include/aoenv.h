@@ -185,6 +185,12 @@ int aoenv_step(AoEnv* env, int i, const void* d_action, void* d_obs, void* d_fra
 int aoenv_run_integrator(AoEnv* env, int i0, int n_steps, double gain, void* d_obs, void* d_frame,
                          void* d_reward, void* d_strehl, void* stream);
 
+/* Replaces: tel.computePSF(zeroPaddingFactor) (OOPAO/Telescope.py:258-357) of the current residual phase (tel.src.phase):
+ * d_psf [n_env][M][M], M = zero_padding * R (even), env dtype: the short-exposure PSF of every env.  As the reference does for even
+ * image sizes (oversampling 2, :303-305), the field is transformed at N = 2 M and |fftshift(fft2(E phasor)) / N|^2 is sum-binned 2 x 2.
+ * Science-path rendering (MAIN/OOPAOEnv/OOPAOEnv.py:473-482, integrator_network.py:93-95); not part of the step. */
+int aoenv_compute_psf(AoEnv* env, int zero_padding, void* d_psf, void* stream);
+
 /* Replaces: the WFS camera settings wfs.cam.{photonNoise, readoutNoise, QE, darkCurrent, integrationTime, FWC, bits, gain,
  * sensor} (OOPAO/Detector.py:19-60; Papyrus: photonNoise = True, MAIN/OOPAOEnv/OOPAOEnv.py:379; Razor:
  * OOPAOEnvRazor.py:243-250, 333).  The frame of every measurement then goes through integrate() + readout()

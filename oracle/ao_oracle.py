@@ -608,6 +608,42 @@ class OraclePyramid:
 
 
 # --------------------------------------------------------------------------------------
+# Science-path PSF                                          (OOPAO/Telescope.py:258-357)
+# --------------------------------------------------------------------------------------
+def telescope_psf(pupil: np.ndarray, flux_map: np.ndarray, phase: np.ndarray, zero_padding: int = 2) -> np.ndarray:
+    """tel.computePSF(zeroPaddingFactor) with no detector and no spatial filter (img_resolution = zeroPaddingFactor *
+    resolution): PropagateField (:296-351) of E = pupil * sqrt(src.fluxMap) * exp(i phase).  Kept quirk: the parity rule
+    ``if oversampling % 2 != img_resolution % 2: oversampling += 1`` (:303-305) turns the default oversampling 1 into 2 for
+    every even image size, so the transform runs at N = 2 * zeroPaddingFactor * resolution and the PSF is its 2 x 2
+    sum-binned |.|^2.  The phasor is complex64 in the reference (:316)."""
+    R = pupil.shape[0]
+    img_resolution = zero_padding * R
+    oversampling = 1
+    if zero_padding * oversampling < 2:
+        oversampling = int(np.ceil(2.0 / zero_padding))                                      # :299-300
+    if oversampling % 2 != img_resolution % 2:
+        oversampling += 1                                                                    # :303-305
+    img_size = int(np.ceil(img_resolution * oversampling))
+    N = int(np.fix(zero_padding * oversampling * R))
+    pad = int(np.ceil((N - R) / 2))                                                          # :308
+    amp = pupil * np.sqrt(flux_map)                                                          # :278 (pupilReflectivity = 1)
+    sup = np.pad(amp * np.exp(1j * phase), ((pad, pad), (pad, pad)), constant_values=0)      # :310-311
+    N = sup.shape[0]
+    xx, yy = np.meshgrid(np.linspace(0, N - 1, N), np.linspace(0, N - 1, N), copy=False)
+    phasor = np.exp(-1j * np.pi / N * (xx + yy) * (1 - img_resolution % 2)).astype(np.complex64)   # :315-316
+    emf = np.fft.fftshift(1 / N * np.fft.fft2(np.fft.ifftshift(sup * phasor)))               # :319
+    shift_pix = 0 if N % 2 == img_size % 2 else (1 if N % 2 == 0 else -1)                    # :322-328
+    lo = int(np.ceil(N / 2) - img_size // 2 + (1 - N % 2) - 1)
+    hi = int(np.ceil(N / 2) + img_size // 2 + shift_pix)                                     # :333-336
+    emf = emf[lo:hi, lo:hi]
+    psf = np.abs(emf) ** 2
+    if oversampling != 1:                                                                    # :341-343, tools.set_binning (sum)
+        m = psf.shape[0] // oversampling
+        psf = psf.reshape(m, oversampling, m, oversampling).sum(-1).sum(1)
+    return psf
+
+
+# --------------------------------------------------------------------------------------
 # Detector                                                   (OOPAO/Detector.py:178-301)
 # --------------------------------------------------------------------------------------
 class Detector:

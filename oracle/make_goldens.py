@@ -246,6 +246,29 @@ def make_detector(ref):
     print(f"detector: wrote {path}")
 
 
+def make_psf(ref):
+    """The reference's Telescope.computePSF (OOPAO/Telescope.py:258-357) of a smooth + random residual phase, R = 24,
+    zero-padding 2 and 4."""
+    from numpy.random import RandomState
+    with RL.quiet():
+        tel = ref.Telescope(resolution=24, diameter=1.6, samplingTime=1 / 500, centralObstruction=0)
+        ngs = ref.Source(optBand="I", magnitude=8)
+        ngs * tel
+    rs = RandomState(8)
+    y, x = np.mgrid[0:24, 0:24] / 24.0
+    opd = (300e-9 * (x - 0.3) ** 2 - 200e-9 * x * y + 40e-9 * rs.normal(size=(24, 24)))
+    tel.OPD = opd * tel.pupil                                         # sets tel.src.phase = OPD * 2 pi / lambda
+    out = {"pupil": np.asarray(tel.pupil, dtype=np.float64), "flux_map": np.asarray(tel.src.fluxMap, dtype=np.float64),
+           "phase": np.asarray(tel.src.phase, dtype=np.float64)}
+    for zp in (2, 4):
+        with RL.quiet():
+            tel.computePSF(zp)
+        out[f"psf_zp{zp}"] = np.asarray(tel.PSF, dtype=np.float64)
+    path = os.path.join(GOLD, "psf.npz")
+    np.savez_compressed(path, **out)
+    print(f"psf: wrote {path}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -258,6 +281,8 @@ def main():
         make_case(ref, name)
     if args.only in (None, "detector"):
         make_detector(ref)
+    if args.only in (None, "psf"):
+        make_psf(ref)
 
 
 if __name__ == "__main__":

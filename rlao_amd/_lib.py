@@ -58,6 +58,7 @@ EXPORTS = {
                              C.c_void_p]),
     "aoenv_run_integrator": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p]),
+    "aoenv_compute_psf": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "aoenv_set_detector": (C.c_int, [C.c_void_p, C.c_void_p]),
     "aoenv_set_return_accumulator": (C.c_int, [C.c_void_p, C.c_void_p]),
     "aoenv_buffer": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),

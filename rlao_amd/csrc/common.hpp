@@ -218,7 +218,12 @@ struct PyrArgs {
     T* frame;              // [E][cam*cam]
     FftPlan plan;
     int R, N, cam, off, centering, theta0, n_theta_chunk, n_env, seq_per_block;
+    int phasor_mult;       // the pupil field is multiplied by exp(-i pi m (x + y) / N) on the padded grid: m = N + 1 (Pyramid with a
+                           // centred mask, Pyramid.py:294), 1 (science PSF, Telescope.py:316), 0 (none)
 };
+// science-path PSF (Telescope.computePSF): |FFT2 of the zero-padded pupil field|^2 / N^2, fftshifted, into psf [E][N][N]
+template <typename T>
+int launch_psf(const PyrArgs<T>& base, T* psf, hipStream_t st);
 template <typename T>
 struct PyrSlopeArgs {
     const T* frame;          // [E][cam*cam]

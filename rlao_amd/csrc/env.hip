@@ -343,6 +343,7 @@ int run_wfs(AoEnv* env, hipStream_t st) {
         pa.cam = env->c.cam_res;
         pa.off = env->c.pyr_n_res / 2 - env->R / 2;
         pa.centering = env->c.pyr_centering;
+        pa.phasor_mult = env->c.pyr_centering ? env->c.pyr_n_res + 1 : 0;
         pa.n_env = env->E;
         PyrSlopeArgs<T> sl{};
         sl.frame = env->as<T>(env->frame);
@@ -1136,6 +1137,57 @@ int aoenv_run_integrator(AoEnv* env, int i0, int n_steps, double gain, void* d_o
         AO_TRY(AO_DISPATCH(env, step_t, env, i0 + k, d_obs /*unused*/, d_obs, k == n_steps - 1 ? d_frame : nullptr, d_reward,
                            d_strehl, gain, st));
     return 0;
+}
+
+extern "C++" {
+template <typename T>
+static int compute_psf_t(AoEnv* env, int zp, void* d_psf, hipStream_t st) {
+    // the reference runs the transform at oversampling 2 for every even image size and sum-bins |.|^2 2 x 2 (Telescope.py:303-305)
+    const int R = env->R, N = 2 * zp * R;
+    const size_t R2 = (size_t)R * R;
+    // scratch of one call: amplitude pupil * sqrt(src.fluxMap) (= the SH field amplitude; the Pyramid's is per modulation
+    // point), twiddles, first-pass output
+    TmpFree tmp;
+    T *d_amp, *d_tw;
+    void* d_t1;
+    AO_TRY(tmp.get((void**)&d_amp, R2 * sizeof(T)));
+    AO_TRY(tmp.get((void**)&d_tw, (size_t)2 * N * sizeof(T)));
+    AO_TRY(tmp.get(&d_t1, (size_t)env->E * R * N * 2 * sizeof(T)));
+    if (env->h_amp.size() != R2) return fail("the WFS amplitude has not been uploaded");
+    const double scale = env->c.wfs_type == AOENV_WFS_PYRAMID ? std::sqrt((double)env->c.pyr_n_theta) : 1.0;
+    std::vector<T> amp(R2), tw(2 * (size_t)N);
+    for (size_t q = 0; q < R2; ++q) amp[q] = (T)(env->h_amp[q] * scale);
+    const double pi = 3.14159265358979323846;
+    for (int k = 0; k < N; ++k) { tw[2 * k] = (T)std::cos(2 * pi * k / N); tw[2 * k + 1] = (T)(-std::sin(2 * pi * k / N)); }
+    AO_HIP(hipMemcpyAsync(d_amp, amp.data(), R2 * sizeof(T), hipMemcpyHostToDevice, st));
+    AO_HIP(hipMemcpyAsync(d_tw, tw.data(), tw.size() * sizeof(T), hipMemcpyHostToDevice, st));
+    PyrArgs<T> pa{};
+    AO_TRY(make_fft_plan(N, &pa.plan));
+    pa.phase = env->as<T>(env->phase);
+    pa.amp = d_amp;
+    pa.tt = nullptr;
+    pa.tw = d_tw;
+    pa.t1 = reinterpret_cast<cx<T>*>(d_t1);
+    pa.R = R;
+    pa.N = N;
+    pa.off = N / 2 - R / 2;                                        // pad_width = (N - R) / 2
+    pa.phasor_mult = 1;                                            // exp(-i pi / N (x + y)): even image sizes (Telescope.py:316)
+    pa.n_env = env->E;
+    AO_TRY(launch_psf<T>(pa, static_cast<T*>(d_psf), st));
+    AO_HIP(hipStreamSynchronize(st));                              // the scratch is released on return
+    return 0;
+}
+}  // extern "C++"
+
+int aoenv_compute_psf(AoEnv* env, int zero_padding, void* d_psf, void* stream) {
+    AO_CHECK_ENV(env);
+    if (!d_psf) return fail("null psf");
+    if (zero_padding < 1 || zero_padding > 8) return fail("zeroPaddingFactor %d outside [1, 8]", zero_padding);
+    if ((zero_padding * env->R) % 2) return fail("odd image sizes are not built");
+    if (2 * zero_padding * env->R > 8192) return fail("PSF transform length %d too long", 2 * zero_padding * env->R);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    return env->c.dtype == AOENV_F32 ? compute_psf_t<float>(env, zero_padding, d_psf, st)
+                                     : compute_psf_t<double>(env, zero_padding, d_psf, st);
 }
 
 int aoenv_set_detector(AoEnv* env, const AoDetector* cfg) {

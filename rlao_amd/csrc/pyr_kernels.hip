@@ -45,7 +45,7 @@ __global__ void __launch_bounds__(256) k_pyr_rows(const PyrArgs<T> a) {
                 if (tt) ang += tt[p];
                 // centred mask: the field is multiplied by exp(-i pi (N+1)/N (x + y)) on the padded grid (Pyramid.py:294, 486)
                 // the angle pi (N+1) k / N is reduced mod 2 pi in integers (k up to 2N would cost float32 1e-4 rad)
-                if (a.centering) ang -= pi_over_n * (T)(((N + 1) * (xg + y0 + r + a.off)) % (2 * N));
+                if (a.phasor_mult) ang -= pi_over_n * (T)((a.phasor_mult * (xg + y0 + r + a.off)) % (2 * N));
                 T s, c;
                 sincos_g<T>(ang, &s, &c);
                 v = {am * c, am * s};
@@ -95,6 +95,72 @@ __global__ void __launch_bounds__(256) k_pyr_cols(const PyrArgs<T> a) {
         t2[(size_t)ky * N + jx0 + c] = r[c * N + ky];
     }
 }
+
+// Science PSF, second pass: grid = (N / CB, 1, E); forward FFT along y of CB columns of T1, |.|^2 / N^2 with the output
+// fftshift.  EMF = fftshift(fft2(ifftshift(E phasor))) / N (OOPAO/Telescope.py:316-319): the input ifftshift only flips
+// signs of the spectrum, which |.|^2 does not see.
+template <typename T>
+__global__ void __launch_bounds__(256) k_psf_cols(const PyrArgs<T> a, T* __restrict__ psf) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int N = a.N, R = a.R, CB = a.seq_per_block;
+    cx<T>* A = reinterpret_cast<cx<T>*>(lds_raw);
+    cx<T>* B = A + CB * N;
+    cx<T>* twl = B + CB * N;
+    fft_load_twiddles<T>(twl, a.tw, N);
+    const int e = blockIdx.z, kx0 = blockIdx.x * CB;
+    const cx<T>* t1 = a.t1 + (size_t)e * R * N;
+    for (int i = threadIdx.x; i < CB * N; i += blockDim.x) A[i] = {0, 0};
+    __syncthreads();
+    for (int i = threadIdx.x; i < R * CB; i += blockDim.x) {
+        const int y = i / CB, c = i - y * CB;
+        A[c * N + a.off + y] = t1[(size_t)y * N + kx0 + c];
+    }
+    cx<T>* f = fft_lds<T>(A, B, a.plan, CB, twl, 0);
+    // 2 x 2 sum-binning of |.|^2 (the reference's oversampling quirk, Telescope.py:303-305, 341-343): the PSF is M x M, M = N / 2
+    const int h = N / 2, M = N / 2;
+    const T scale = (T)1 / ((T)N * (T)N);
+    T* out = psf + (size_t)e * M * M;
+    const int jx0 = (kx0 + h) % N;                                // CB (even) divides N / 2: the block's columns stay contiguous
+    for (int i = threadIdx.x; i < M * (CB / 2); i += blockDim.x) {
+        const int k2 = i / (CB / 2), c2 = i - k2 * (CB / 2);     // output row k2, column (jx0 / 2) + c2
+        T acc = 0;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const cx<T> v = f[(2 * c2 + dx) * N + (2 * k2 + dy + h) % N];   // shifted row ky holds frequency (ky + h) mod N
+                acc += (v.re * v.re + v.im * v.im) * scale;
+            }
+        out[(size_t)k2 * M + jx0 / 2 + c2] = acc;
+    }
+}
+
+template <typename T>
+int launch_psf(const PyrArgs<T>& base, T* psf, hipStream_t st) {
+    PyrArgs<T> a = base;
+    const int N = a.N, R = a.R;
+    int rb = (int)(64 * 1024 / (2 * (size_t)N * sizeof(cx<T>)));
+    if (rb < 1) return fail("psf: N = %d does not fit two LDS row buffers", N);
+    rb = rb > 8 ? 8 : rb;
+    int cb = rb & ~1;
+    while (cb > 2 && (N / 2) % cb) cb -= 2;
+    if (cb < 2 || (N / 2) % cb || (N / 2) % 2) return fail("psf: N = %d has no even column block", N);
+    const size_t lds1 = (size_t)(2 * rb * N + N) * sizeof(cx<T>), lds2 = (size_t)(2 * cb * N + N) * sizeof(cx<T>);
+    if (lds1 > 64 * 1024)
+        AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyr_rows<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+    if (lds2 > 64 * 1024)
+        AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_psf_cols<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    a.theta0 = 0;
+    a.n_theta_chunk = 1;
+    a.seq_per_block = rb;
+    hipLaunchKernelGGL(k_pyr_rows<T>, dim3(cdiv(R, rb), 1, a.n_env), dim3(256), lds1, st, a);
+    a.seq_per_block = cb;
+    hipLaunchKernelGGL(k_psf_cols<T>, dim3(N / cb, 1, a.n_env), dim3(256), lds2, st, a, psf);
+    AO_HIP(hipGetLastError());
+    return 0;
+}
+template int launch_psf<float>(const PyrArgs<float>&, float*, hipStream_t);
+template int launch_psf<double>(const PyrArgs<double>&, double*, hipStream_t);
 
 // P3: grid = (cam, E); the nb = N / cam rows of one camera row, all modulation points of the chunk
 template <typename T>

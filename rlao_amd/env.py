@@ -298,7 +298,21 @@ class _TelProxy:
         return e._fetch(L.B_PHASE, (e.R, e.R)) * (e.src_wavelength / (2 * np.pi))
 
     def computePSF(self, zeroPaddingFactor=2):
-        raise NotImplementedError("the science-path PSF is SURVEY.md row f2 (next), not part of the step hot path")
+        """tel.computePSF (OOPAO/Telescope.py:258-357) of the current residual phase, on the device: sets ``tel.PSF``
+        ([n_envs, M, M] tensor, M = zeroPaddingFactor * resolution; a NumPy array for the single-env flavour) and
+        ``tel.PSF_norma``."""
+        e = self._e
+        torch = _torch()
+        M = int(zeroPaddingFactor) * e.R
+        psf = torch.empty((e.n_envs, M, M), device=e.device, dtype=e.tdtype)
+        L.check(e._shard.lib.aoenv_compute_psf(e._shard.h, int(zeroPaddingFactor), C.c_void_p(psf.data_ptr()), C.c_void_p(e._stream())))
+        if e.output == "numpy":
+            self.PSF = psf[0].double().cpu().numpy()
+            self.PSF_norma = self.PSF / self.PSF.max()
+        else:
+            self.PSF = psf
+            self.PSF_norma = psf / psf.amax(dim=(1, 2), keepdim=True)
+        return self.PSF
 
 
 # ----------------------------------------------------------------------------------------------------

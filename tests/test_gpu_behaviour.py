@@ -309,3 +309,27 @@ def test_checkpoint_resume_is_bitwise(noise):
     assert torch.equal(obs_a, obs_c) and torch.equal(rew_a, rew_c) and torch.equal(sr_a, sr_c)
     np.testing.assert_array_equal(env2.get_state()["screen"], maps_a)
     env2.close()
+
+
+@pytest.mark.parametrize("dtype,tol", [("f64", 2e-7), ("f32", 2e-5)])
+def test_science_psf_matches_oracle(dtype, tol):
+    """env.tel.computePSF(zp) (aoenv_compute_psf: zero-padded pupil FFT, 2 x 2 binned) against the oracle's restatement of
+    Telescope.computePSF, on the residual phase of a stepped loop; float64 differs from the reference only by its
+    complex64 phasor (6e-8 relative)."""
+    import torch
+    from oracle import ao_oracle as O                       # checker only
+    from rlao_amd import _lib as L
+    from rlao_amd.env import BatchedAOEnv
+    env = BatchedAOEnv(n_envs=3, device=0, dtype=dtype)
+    env.set_params(SMALL, wfs_type="shackhartmann")
+    out = _run(env, 4, 9)
+    phase = env._shard.download(L.B_PHASE, (3, env.R, env.R)).astype(np.float64)
+    flux = env._sh_tables.flux_map
+    for zp in (2, 3):
+        psf = env.tel.computePSF(zp)
+        torch.cuda.synchronize()
+        assert tuple(psf.shape) == (3, zp * env.R, zp * env.R)
+        for e in range(3):
+            want = O.telescope_psf(env.pupil.astype(float), flux, phase[e], zp)
+            np.testing.assert_allclose(psf[e].double().cpu().numpy(), want, rtol=0, atol=tol * want.max())
+    env.close()

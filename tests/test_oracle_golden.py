@@ -117,3 +117,11 @@ def test_detector_matches_reference(golden_dir):
         det = O.Detector(**c)
         det.rs_photon, det.rs_readout, det.rs_dark = RandomState(11), RandomState(12), RandomState(13)
         np.testing.assert_array_equal(det.integrate(g["frame"]), g[name], err_msg=name)
+
+
+def test_science_psf_matches_reference(golden_dir):
+    """oracle.telescope_psf == the reference's Telescope.computePSF (incl. its oversampling-2 quirk for even images)."""
+    g = np.load(os.path.join(golden_dir, "psf.npz"))
+    for zp in (2, 4):
+        got = O.telescope_psf(g["pupil"], g["flux_map"], g["phase"], zp)
+        np.testing.assert_allclose(got, g[f"psf_zp{zp}"], rtol=0, atol=1e-12 * g[f"psf_zp{zp}"].max())
