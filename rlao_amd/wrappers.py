@@ -74,3 +74,102 @@ class TimeDelayEnv:
         out = self._env.step(i, self.action_buffer[0])
         del self.action_buffer[0]
         return out
+
+
+class Box:
+    """Minimal stand-in for ``gym.spaces.Box`` (gymnasium is not a dependency of the env)."""
+
+    def __init__(self, low, high, shape, dtype="float32"):
+        self.low, self.high, self.shape, self.dtype = low, high, tuple(shape), dtype
+
+    def __repr__(self):
+        return f"Box({self.low}, {self.high}, {self.shape}, {self.dtype})"
+
+
+class HistoryEnv:
+    """gymnasium-style facade with the observation history kept on the device
+    (MAIN/OOPAOEnv/OOPAOEnv_VPG.py:77-95 spaces, :553-608 step, :660-681 roll_buffer):
+
+    * ``step(action) -> (obs_history, reward, terminated, truncated, info)`` -- no frame index argument; the wrapper
+      counts frames itself (and wraps at ``nLoop``, the length of the env's telemetry);
+    * ``obs_history`` is ``[n_envs, n_history, nAct, nAct]`` (``[n_history, nAct, nAct]`` for one env), newest image
+      at index 0, rolled one slot per step;
+    * the reward is the Strehl ratio (``reward = strehl``, :601-603);
+    * actions pass through a FIFO of ``delay`` frames (``action_buffer``, :562-566), a 1-D action is first scattered to
+      the actuator image (``vec_to_img``, :559-560).
+
+    Nothing leaves the device for a batched env; for the single-env NumPy flavour the history is returned as a NumPy
+    array like the reference's ``obs_history.cpu().numpy()``."""
+
+    def __init__(self, env, n_history=20, delay=1):
+        if delay < 1:
+            raise ValueError("delay must be >= 1 (the reference applies action_buffer[0] after appending the new action)")
+        self._env = env
+        self.env = env
+        self.n_history = int(n_history)
+        self.delay = int(delay)
+        self.t = 0
+        A = env.nActuator
+        self.single = getattr(env, "output", "torch") == "numpy"
+        lead = () if self.single or env.n_envs == 1 else (env.n_envs,)
+        self.observation_space = Box(-float("inf"), float("inf"), lead + (self.n_history, A, A))
+        self.action_space = Box(-10.0, 10.0, lead + (A, A))
+        self._alloc()
+
+    def __getattr__(self, name):
+        return getattr(self._env, name)
+
+    def _alloc(self):
+        torch = _torch()
+        e = self._env
+        dev = getattr(e, "device", "cpu")
+        n = 1 if self.single else e.n_envs
+        A = e.nActuator
+        self.obs_history = torch.zeros((n, self.n_history, A, A), device=dev, dtype=torch.float32)
+        self.action_buffer = [torch.zeros((n, A, A), device=dev, dtype=torch.float32) for _ in range(self.delay - 1)]
+
+    def _out(self):
+        if self.single:
+            return self.obs_history[0].cpu().numpy()
+        return self.obs_history[0] if self._env.n_envs == 1 else self.obs_history
+
+    def reset(self, seed=None, options=None):
+        """New turbulence (``generateNewPhaseScreen(seed)``), flat DM, one measurement, empty histories."""
+        e = self._env
+        e.atm.generateNewPhaseScreen(seed)
+        e.dm.coefs = 0
+        e.tel * e.dm * e.wfs
+        obs = _torch().as_tensor(e.reset_soft(), dtype=_torch().float32)
+        self._alloc()
+        self.t = 0
+        self._push(obs)
+        return self._out(), {}
+
+    def _push(self, obs):
+        torch = _torch()
+        obs = torch.as_tensor(obs, dtype=torch.float32, device=self.obs_history.device)
+        if obs.dim() == 2:
+            obs = obs.unsqueeze(0)
+        self.obs_history = torch.roll(self.obs_history, shifts=1, dims=1)
+        self.obs_history[:, 0] = obs
+
+    def step(self, action):
+        torch = _torch()
+        e = self._env
+        a = torch.as_tensor(action, dtype=torch.float32, device=self.obs_history.device)
+        if a.shape[-1] != e.nActuator or a.dim() == 1 or (a.dim() == 2 and not self.single and e.n_envs > 1):
+            a = e.vec_to_img(a, True)                              # command vector(s) -> actuator image(s)
+        if a.dim() == 2:
+            a = a.unsqueeze(0)
+        self.action_buffer.append(a)
+        act = self.action_buffer.pop(0)
+        n_loop = int(e.param.nLoop) if hasattr(e, "param") else 1 << 30
+        i = self.t % n_loop
+        self.t += 1
+        obs, _, _, strehl, _, info = e.step(i, act[0].cpu().numpy() if self.single else act)
+        self._push(obs)
+        terminated = truncated = False
+        if not self.single and e.n_envs > 1:
+            terminated = torch.zeros(e.n_envs, dtype=torch.bool, device=self.obs_history.device)
+            truncated = terminated.clone()
+        return self._out(), strehl, terminated, truncated, {"strehl": strehl}

@@ -333,3 +333,35 @@ def test_science_psf_matches_oracle(dtype, tol):
             want = O.telescope_psf(env.pupil.astype(float), flux, phase[e], zp)
             np.testing.assert_allclose(psf[e].double().cpu().numpy(), want, rtol=0, atol=tol * want.max())
     env.close()
+
+
+def test_history_env_on_the_device():
+    """HistoryEnv over the real batched env: reset() + steps, history stays on the GPU and matches plain stepping."""
+    import torch
+    from rlao_amd.env import BatchedAOEnv
+    from rlao_amd.wrappers import HistoryEnv
+    env = BatchedAOEnv(n_envs=4, device=0, dtype="f32")
+    env.set_params(SMALL, wfs_type="shackhartmann")
+    h = HistoryEnv(env, n_history=5, delay=1)
+    hist, info = h.reset(seed=3)
+    assert hist.is_cuda and tuple(hist.shape) == (4, 5, env.nActuator, env.nActuator)
+    first = hist[:, 0].clone()
+    acts = []
+    for k in range(3):
+        a = 0.4 * hist[:, 0]
+        acts.append(a.clone())
+        hist, rew, term, trunc, info = h.step(a)
+    # the same episode by hand
+    env.atm.generateNewPhaseScreen(3)
+    env.dm.coefs = 0
+    env.tel * env.dm * env.wfs
+    obs = env.reset_soft()
+    assert torch.equal(obs, first)
+    want = [obs.clone()]
+    for k in range(3):
+        obs, _, _, sr, _, _ = env.step(k, acts[k])
+        want.append(obs.clone())
+    for j in range(4):
+        assert torch.equal(hist[:, j], want[3 - j])
+    assert torch.equal(hist[:, 4], torch.zeros_like(first)) and torch.equal(rew, sr)
+    env.close()

@@ -109,3 +109,48 @@ def test_catmull_rom_weights_match_the_nested_form():
         f = np.array([0.3, -1.2, 2.5, 0.7])
         assert abs(w @ f - O._cubic(x, *f)) < 1e-14
         assert abs(w.sum() - 1) < 1e-14
+
+
+class _FakeBatchedEnv:
+    """Torch env on the CPU with the batched return convention (for HistoryEnv)."""
+    output = "torch"
+    nActuator = 3
+    n_envs = 2
+    device = "cpu"
+
+    def __init__(self):
+        self.seen = []
+        self.param = type("P", (), {"nLoop": 5})()
+
+    def vec_to_img(self, v, use_torch=False):
+        img = torch.zeros(v.shape[:-1] + (3, 3))
+        img[..., [0, 1, 2], [0, 1, 2]] = v
+        return img
+
+    def step(self, i, action):
+        self.seen.append((i, action.clone()))
+        obs = torch.full((2, 3, 3), float(len(self.seen)))
+        return obs, None, -obs.sum(dim=(1, 2)), torch.tensor([0.1, 0.2]) * len(self.seen), torch.zeros(2, dtype=torch.bool), {}
+
+
+def test_history_env_rolls_and_delays():
+    """gymnasium-style facade (MAIN/OOPAOEnv/OOPAOEnv_VPG.py:553-608, 660-681): newest observation at index 0, Strehl as the
+    reward, action FIFO, frame counter wrapping at nLoop, command vectors scattered to images."""
+    from rlao_amd.wrappers import HistoryEnv
+    inner = _FakeBatchedEnv()
+    env = HistoryEnv(inner, n_history=4, delay=2)
+    assert env.observation_space.shape == (2, 4, 3, 3) and env.action_space.shape == (2, 3, 3)
+    for k in range(7):
+        hist, rew, term, trunc, info = env.step(torch.full((2, 3, 3), float(k + 1)))
+    assert hist.shape == (2, 4, 3, 3)
+    assert [float(hist[0, j, 0, 0]) for j in range(4)] == [7.0, 6.0, 5.0, 4.0]      # newest first
+    assert torch.allclose(rew, torch.tensor([0.7, 1.4])) and info["strehl"] is rew
+    assert term.dtype == torch.bool and not bool(term.any()) and not bool(trunc.any())
+    assert [float(a[0, 0, 0]) for _, a in inner.seen] == [0.0, 1.0, 2.0, 3.0, 4.0, 5.0, 6.0]   # one extra frame of delay
+    assert [i for i, _ in inner.seen] == [0, 1, 2, 3, 4, 0, 1]                          # wraps at nLoop = 5
+    env.step(torch.tensor([[1.0, 2.0, 3.0], [4.0, 5.0, 6.0]]))                           # vectors of 3 "actuators"
+    assert inner.seen[-1][1].shape == (2, 3, 3)
+    single = HistoryEnv(_FakeEnv(), n_history=3, delay=1)
+    h, r, t, tr, inf = single.step(np.full((3, 3), 2.0))
+    assert isinstance(h, np.ndarray) and h.shape == (3, 3, 3) and r == 0.25 and t is False
+    assert float(single._env.seen[-1][0, 0]) == 2.0
