@@ -755,7 +755,7 @@ class OracleEnv:
                  r0=0.13, L0=30.0, windSpeed=(10.0,), windDirection=(72.0,), fractionalR0=(1.0,),
                  altitude=(0.0,), mech_coupling=0.35, m2c=None, n_modes=50, light_ratio=None,
                  threshold_cog=0.01, nLoop=10000, leak=0.99, gainCL=0.5, n_meas=6, wfs_type="sh", modulation=0.0,
-                 psf_centering=True):
+                 psf_centering=True, second_dm_nsub=None):
         self.R, self.D, self.dt = resolution, diameter, dt
         self.leak, self.gainCL = leak, gainCL
         self.pupil = make_pupil(resolution)
@@ -770,6 +770,20 @@ class OracleEnv:
         self.dm_mask = dm["validAct"].reshape(self.nActuator, self.nActuator)
         self.xvalid, self.yvalid = np.nonzero(self.dm_mask)
         self.nValidAct = int(dm["validAct"].sum())
+        if second_dm_nsub is not None:
+            # a second DM chained behind the first, tel*dm1*dm2 (Telescope.py:533-544: every DM adds its OPD): one stacked
+            # command vector [dm1 | dm2]; the actuator "image" holds both grids, dm2 below dm1
+            n1, n2 = self.nActuator, second_dm_nsub + 1
+            dm2 = dm_geometry(resolution, diameter, second_dm_nsub, mech_coupling, pitch=diameter / n2)
+            self.dm_modes = np.hstack([dm["modes"], dm2["modes"]])
+            self.nActuator = n1 + n2
+            mask = np.zeros((n1 + n2, n1 + n2), bool)
+            mask[:n1, :n1] = dm["validAct"].reshape(n1, n1)
+            mask[n1:, :n2] = dm2["validAct"].reshape(n2, n2)
+            self.dm_mask = mask
+            self.xvalid, self.yvalid = np.nonzero(mask)
+            self.nValidAct = int(mask.sum())
+            self.gx = self.gy = None
         self.wfs_type = wfs_type
         if wfs_type == "sh":
             self.wfs = OracleSH(n_subap, resolution, diameter, self.pupil, self.wavelength, self.flux_map,

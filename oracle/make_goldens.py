@@ -269,6 +269,40 @@ def make_psf(ref):
     print(f"psf: wrote {path}")
 
 
+def make_two_dm(ref):
+    """Two chained deformable mirrors, tel*dm1*dm2*wfs (OOPAO/Telescope.py:533-544 adds each dm.OPD to tel.OPD_no_pupil while
+    the telescope is paired to the atmosphere): an 8x8 and a 4x4 actuator-pitch DM on the small_sh geometry, three steps of
+    turbulence, random commands on both mirrors."""
+    from numpy.random import RandomState
+    c = CASES["small_sh"]
+    env = build(ref, c)
+    tel, atm, dm1, wfs = env["tel"], env["atm"], env["dm"], env["wfs"]
+    ns2 = 4
+    with RL.quiet():
+        dm2 = ref.DeformableMirror(telescope=tel, nSubap=ns2, mechCoupling=0.35, coordinates=None, pitch=tel.D / (ns2 + 1))
+        atm.generateNewPhaseScreen(seed=21)
+        tel + atm
+    rs = RandomState(4)
+    out = {"cfg_ns2": ns2, "valid2": np.asarray(dm2.validAct, dtype=bool), "modes2_probe": np.asarray(dm2.modes[::37], dtype=np.float64)}
+    c1s, c2s, opds, sigs, atms = [], [], [], [], []
+    for k in range(3):
+        c1 = rs.normal(size=dm1.nValidAct) * 80e-9
+        c2 = rs.normal(size=dm2.nValidAct) * 150e-9
+        with RL.quiet():
+            atm.update()
+            atms.append(np.asarray(tel.OPD_no_pupil, dtype=np.float64).copy())
+            dm1.coefs = c1
+            dm2.coefs = c2
+            tel * dm1 * dm2 * wfs
+        c1s.append(c1); c2s.append(c2)
+        opds.append(np.asarray(tel.OPD, dtype=np.float64).copy())
+        sigs.append(np.asarray(wfs.signal, dtype=np.float64).copy())
+    out.update(coefs1=np.stack(c1s), coefs2=np.stack(c2s), opd_atm=np.stack(atms), opd=np.stack(opds), signal=np.stack(sigs))
+    path = os.path.join(GOLD, "two_dm.npz")
+    np.savez_compressed(path, **out)
+    print(f"two_dm: wrote {path}  (A1 = {dm1.nValidAct}, A2 = {dm2.nValidAct})")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -283,6 +317,8 @@ def main():
         make_detector(ref)
     if args.only in (None, "psf"):
         make_psf(ref)
+    if args.only in (None, "two_dm"):
+        make_two_dm(ref)
 
 
 if __name__ == "__main__":

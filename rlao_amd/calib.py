@@ -239,8 +239,9 @@ class DMTables:
     (OOPAO/DeformableMirror.py:286-305 valid actuators, :494-514 influence model).  With no rotation /
     anamorphosis the influence function of actuator (iy, ix) is gy[:, iy] (x) gx[:, ix]."""
 
-    def __init__(self, p: AOParams, pitch: float | None = None):
-        R, D, ns = p.resolution, p.diameter, p.nSubaperture
+    def __init__(self, p: AOParams, pitch: float | None = None, n_subap: int | None = None):
+        R, D = p.resolution, p.diameter
+        ns = p.nSubaperture if n_subap is None else int(n_subap)      # a second DM has its own actuator pitch
         self.nAct = nAct = ns + 1
         self.pitch = D / nAct if pitch is None else pitch        # MAIN/OOPAOEnv/OOPAOEnv.py:228
         x = np.linspace(-D / 2, D / 2, nAct)
@@ -266,6 +267,30 @@ class DMTables:
         y0 = self._centre[self.act_idx // self.nAct]
         a = self._a
         return np.exp(-(a * (XX.reshape(-1, 1) - x0[None, :]) ** 2 + a * (YY.reshape(-1, 1) - y0[None, :]) ** 2))
+
+
+class CompositeDM:
+    """Two deformable mirrors chained in the beam, ``tel*dm1*dm2*wfs`` (OOPAO/Telescope.py:533-544: every DM adds its OPD;
+    with fov = 0 an altitude-conjugated DM has the ground DM's grid, DeformableMirror.py:388-389).  Presented to the library
+    as ONE dense DM: command vector [dm1 | dm2], influence matrix [modes1 | modes2], and an actuator "image" of side
+    nAct1 + nAct2 that holds dm1's grid on top and dm2's below it (columns 0 .. nAct2-1)."""
+
+    def __init__(self, p: AOParams, n_subap_2: int):
+        self.dm1, self.dm2 = DMTables(p), DMTables(p, n_subap=n_subap_2)
+        n1, n2 = self.dm1.nAct, self.dm2.nAct
+        self.nAct = n1 + n2
+        mask = np.zeros((self.nAct, self.nAct), bool)
+        mask[:n1, :n1] = self.dm1.dm_mask
+        mask[n1:, :n2] = self.dm2.dm_mask
+        self.dm_mask = mask
+        self.validAct = mask.reshape(-1)
+        self.act_idx = np.flatnonzero(self.validAct).astype(np.int32)
+        self.nValidAct = int(self.act_idx.size)
+        self.xvalid, self.yvalid = np.nonzero(mask)
+        self.gx = self.gy = None                                   # not separable as a whole
+
+    def dense_modes(self) -> np.ndarray:
+        return np.hstack([self.dm1.dense_modes(), self.dm2.dense_modes()])
 
 
 # ------------------------------------------------------------------------------------------------------

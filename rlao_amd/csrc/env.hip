@@ -377,9 +377,13 @@ int run_wfs(AoEnv* env, hipStream_t st) {
     return 0;
 }
 
+// dm.OPD = modes @ coefs for a dense (non-separable, e.g. two chained mirrors) DM: [E][R^2] = coefs [E][A] . modes [R^2][A]^T
 template <typename T>
 int refresh_dense_dm(AoEnv* env, hipStream_t st) {
     if (env->c.dm_separable) return 0;
+    if (sizeof(T) == 4 && env->use_mfma)                           // one K slice: the product lands in dm_opd directly
+        return launch_gemm_nt_mfma(reinterpret_cast<const float*>(env->coefs), reinterpret_cast<const float*>(env->modes),
+                                   reinterpret_cast<float*>(env->dm_opd), env->E, env->R * env->R, env->A, env->A, env->A, 1, st);
     return launch_gemm_nt<T>(env->as<T>(env->coefs), env->as<T>(env->modes), env->as<T>(env->dm_opd), env->E,
                              env->R * env->R, env->A, env->A, env->A, env->R * env->R, st);
 }

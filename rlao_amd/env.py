@@ -378,9 +378,11 @@ class BatchedAOEnv:
         """Kept for call compatibility (MAIN/PO4AO/mbrl.py:27); the parameters come from ``set_params``."""
         self.param_file, self.oopao_path = param_file, oopao_path
 
-    def set_params(self, args=None, wfs_type="pyramid", modal_basis="zernike", gainCL=0.5, m2c=None, **kw):
+    def set_params(self, args=None, wfs_type="pyramid", modal_basis="zernike", gainCL=0.5, m2c=None, second_dm=None, **kw):
         """Builds the loop (MAIN/OOPAOEnv/OOPAOEnv.py:93-385).  ``wfs_type`` is "pyramid" (the reference's default,
-        Papyrus) or "shackhartmann" (OOPAOEnvRazor.py:232-238)."""
+        Papyrus) or "shackhartmann" (OOPAOEnvRazor.py:232-238).  ``second_dm=dict(nSubaperture=n)`` chains a second DM of
+        that pitch behind the first (``tel*dm1*dm2*wfs``, BASELINE configs[4]): commands, observations and actions then
+        cover both mirrors (``calib.CompositeDM``: one stacked actuator image), through the dense-DM kernels."""
         if wfs_type in ("shackhartmann", "sh"):
             self.wfs_type = "sh"
         elif wfs_type in ("pyramid", "pyr"):
@@ -395,7 +397,9 @@ class BatchedAOEnv:
         self.pupil = calib.telescope_pupil(self.R, p.centralObstruction)
         self.src_wavelength, self.nPhoton = calib.source(p.opticalBand, p.magnitude)
         self._atm_tables = calib.AtmosphereTables(p)
-        self._dm_tables = dmt = calib.DMTables(p)
+        self._dm_tables = dmt = (calib.DMTables(p) if not second_dm else
+                                 calib.CompositeDM(p, int(second_dm["nSubaperture"])))
+        self._dm_separable = 0 if second_dm else 1
         self.nActuator, self.nValidAct = dmt.nAct, dmt.nValidAct
         self.dm_mask = dmt.dm_mask.astype(int)
         self.xvalid, self.yvalid = dmt.xvalid, dmt.yvalid
@@ -456,7 +460,7 @@ class BatchedAOEnv:
         valid_idx = self._wfs_valid_idx
         cfg = dict(dtype=L.F32 if dtype == "f32" else L.F64, n_env=n_env, resolution=self.R, n_layer=n_layer,
                    layer_res=at.N, n_inner=at.n_inner, n_outer=at.n_outer, n_act=dmt.nAct, n_valid_act=dmt.nValidAct,
-                   dm_separable=1, n_subap=p.nSubaperture, n_valid_subap=len(valid_idx), n_signal=2 * len(valid_idx),
+                   dm_separable=self._dm_separable, n_subap=p.nSubaperture, n_valid_subap=len(valid_idx), n_signal=2 * len(valid_idx),
                    cam_res=self.cam_res, n_loop=int(p.nLoop), max_group=max_group,
                    atm_wavelength=calib.ATM_WAVELENGTH, src_wavelength=self.src_wavelength, leak=p.leak,
                    threshold_cog=p.threshold_cog)
@@ -468,8 +472,11 @@ class BatchedAOEnv:
                        pyr_centering=int(pt.psf_centering), pyr_norm_valid=pt.norm_valid, pyr_q_lo=pt.q_lo, pyr_q_hi=pt.q_hi)
         sh = Shard(cfg, self.device_index)
         sh.upload(L.C_PUPIL, self.pupil.astype(np.uint8))
-        sh.upload(L.C_DM_GX, dmt.gx)
-        sh.upload(L.C_DM_GY, dmt.gy)
+        if self._dm_separable:
+            sh.upload(L.C_DM_GX, dmt.gx)
+            sh.upload(L.C_DM_GY, dmt.gy)
+        else:
+            sh.upload(L.C_DM_MODES, dmt.dense_modes())
         sh.upload(L.C_ACT_IDX, dmt.act_idx)
         sh.upload(L.C_SH_SUBAP_IDX, valid_idx)
         if self.wfs_type == "sh":

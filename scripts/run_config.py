@@ -19,11 +19,12 @@ CONFIGS = {
     # ELT scale 39 m / 80x80 SH, 4096 envs over 8 GPUs = 512 per GPU
     "C4": dict(wfs="shackhartmann", n_envs=512, geo=dict(diameter=39.0, nSubaperture=80, nPixelPerSubap=6, r0=0.13, L0=30.0,
                windSpeed=[10.0], windDirection=[72.0], fractionalR0=[1.0], altitude=[0.0], nModes=300)),
-    # 3-layer atmosphere, C2 geometry, 2048 envs over 8 GPUs = 256 per GPU (the dual DM of the config is not built)
-    "C5": dict(wfs="shackhartmann", n_envs=256, geo=dict(diameter=8.0, nSubaperture=20, nPixelPerSubap=6, r0=0.13, L0=30.0,
+    # 3-layer atmosphere + two chained DMs (20x20 and 10x10 actuator pitch), C2 geometry, 2048 envs over 8 GPUs = 256 per GPU
+    "C5": dict(wfs="shackhartmann", n_envs=256, second_dm=dict(nSubaperture=10), geo=dict(diameter=8.0, nSubaperture=20, nPixelPerSubap=6, r0=0.13, L0=30.0,
                windSpeed=[10.0, 12.0, 11.0], windDirection=[0.0, 72.0, 144.0], fractionalR0=[0.45 / 0.65, 0.1 / 0.65, 0.1 / 0.65],
                altitude=[0.0, 1000.0, 5000.0], nModes=50)),
 }
+CONFIGS["C5_1dm"] = dict(CONFIGS["C5"], second_dm=None)         # the same atmosphere with the single 20x20 DM (fused step kernel)
 
 
 def main():
@@ -33,7 +34,7 @@ def main():
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else 60
     t0 = time.perf_counter()
     env = BatchedAOEnv(n_envs=n, device=0, dtype="f32", return_frame=False, env_seed_stride=0)
-    env.set_params(dict(cfg["geo"], nLoop=steps + 40), wfs_type=cfg["wfs"])
+    env.set_params(dict(cfg["geo"], nLoop=steps + 40), wfs_type=cfg["wfs"], second_dm=cfg.get("second_dm"))
     t_init = time.perf_counter() - t0
     print(f"[{name}] init {t_init:.1f} s: R={env.R} A={env.nValidAct} nSignal={env.nSignal} cam={env.cam_res}", file=sys.stderr, flush=True)
     env.generate_new_phase_screen(17)
@@ -43,7 +44,7 @@ def main():
     obs = env.reset_soft()
     # float64 reference shard of 1 env, same seed: one measurement
     e64 = BatchedAOEnv(n_envs=1, device=0, dtype="f64", return_frame=False)
-    e64.set_params(dict(cfg["geo"], nLoop=8), wfs_type=cfg["wfs"])
+    e64.set_params(dict(cfg["geo"], nLoop=8), wfs_type=cfg["wfs"], second_dm=cfg.get("second_dm"))
     e64.generate_new_phase_screen(17)
     e64.dm.coefs = 0
     e64.measure()

@@ -365,3 +365,47 @@ def test_history_env_on_the_device():
         assert torch.equal(hist[:, j], want[3 - j])
     assert torch.equal(hist[:, 4], torch.zeros_like(first)) and torch.equal(rew, sr)
     env.close()
+
+
+def test_two_dms_match_reference_and_oracle(golden_dir):
+    """BASELINE configs[4] hook: two chained DMs (tel*dm1*dm2*wfs).  (a) float64 measurement of the reference's recorded
+    atmosphere OPD + commands on both mirrors against the reference's own signal (tests/golden/two_dm.npz); (b) a closed
+    loop over both mirrors against the oracle."""
+    import torch
+    from oracle import ao_oracle as O                       # checker only
+    from rlao_amd import _lib as L
+    from rlao_amd.env import BatchedAOEnv
+    g = np.load(os.path.join(golden_dir, "two_dm.npz"))
+    ns2 = int(g["cfg_ns2"])
+    env = BatchedAOEnv(n_envs=3, device=0, dtype="f64")
+    env.set_params(SMALL, wfs_type="shackhartmann", second_dm=dict(nSubaperture=ns2))
+    A1, A2 = g["coefs1"].shape[1], g["coefs2"].shape[1]
+    assert env.nValidAct == A1 + A2 and env.nActuator == 9 + ns2 + 1
+    env._shard.set_atm_opd(g["opd_atm"].reshape(3, -1))
+    env._shard.set_coefs(np.concatenate([g["coefs1"], g["coefs2"]], axis=1))
+    env.measure()
+    sig = env._shard.download(L.B_SIGNAL, (3, env.nSignal))
+    np.testing.assert_allclose(sig, g["signal"], rtol=0, atol=1e-8)
+    opd = env._shard.download(L.B_PHASE, (3, env.R, env.R)) * (env.src_wavelength / (2 * np.pi))
+    np.testing.assert_allclose(opd, g["opd"], rtol=0, atol=1e-15)
+    env.close()
+    for dtype, tol in (("f64", 1e-6), ("f32", 5e-5)):
+        env = BatchedAOEnv(n_envs=2, device=0, dtype=dtype)
+        env.set_params(SMALL, wfs_type="shackhartmann", second_dm=dict(nSubaperture=ns2))
+        ref = O.OracleEnv(resolution=48, diameter=3.2, n_subap=8, r0=0.13, L0=30.0, windSpeed=[10.0], windDirection=[72.0],
+                          fractionalR0=[1.0], altitude=[0.0], m2c=env.M2C_CL, n_modes=20, second_dm_nsub=ns2)
+        env.generate_new_phase_screen(13)
+        env.dm.coefs = 0
+        env.measure()
+        obs = env.reset_soft()
+        ref.new_episode(13)
+        o_obs = ref.reset_soft()
+        np.testing.assert_allclose(obs[0].cpu().numpy(), o_obs, atol=tol)
+        for i in range(6):
+            act = (0.5 * obs).float()
+            obs, frame, rew, sr, done, info = env.step(i, act)
+            o_obs, _, o_rew, o_sr, _, _ = ref.step(i, act[0].cpu().numpy())
+            np.testing.assert_allclose(obs[0].cpu().numpy(), o_obs, atol=tol)
+            assert abs(float(sr[0]) - o_sr) < tol
+        assert float(torch.abs(env.dm.coefs if torch.is_tensor(env.dm.coefs) else torch.as_tensor(env.dm.coefs)).max()) > 0
+        env.close()

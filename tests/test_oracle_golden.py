@@ -125,3 +125,18 @@ def test_science_psf_matches_reference(golden_dir):
     for zp in (2, 4):
         got = O.telescope_psf(g["pupil"], g["flux_map"], g["phase"], zp)
         np.testing.assert_allclose(got, g[f"psf_zp{zp}"], rtol=0, atol=1e-12 * g[f"psf_zp{zp}"].max())
+
+
+def test_two_chained_dms_match_reference(golden_dir):
+    """tel*dm1*dm2*wfs of the reference (every DM adds its OPD, Telescope.py:533-544) == the oracle's stacked command vector
+    [dm1 | dm2] with the stacked influence matrix: residual OPD and Shack-Hartmann signal over three turbulence steps."""
+    g = np.load(os.path.join(golden_dir, "two_dm.npz"))
+    env = O.OracleEnv(resolution=48, diameter=3.2, n_subap=8, r0=0.13, L0=30.0, windSpeed=[10.0], windDirection=[72.0],
+                      fractionalR0=[1.0], altitude=[0.0], n_modes=20, second_dm_nsub=int(g["cfg_ns2"]))
+    assert env.nValidAct == g["coefs1"].shape[1] + g["coefs2"].shape[1] and env.nActuator == 9 + 5
+    for k in range(3):
+        cf = np.concatenate([g["coefs1"][k], g["coefs2"][k]])
+        opd = (g["opd_atm"][k] + env.dm_opd(cf)) * env.pupil
+        np.testing.assert_allclose(opd, g["opd"][k], rtol=0, atol=1e-18)
+        sig = env.wfs.measure(opd * 2 * np.pi / env.wavelength)
+        np.testing.assert_allclose(sig, g["signal"][k], rtol=0, atol=1e-10)
