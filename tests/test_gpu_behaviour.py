@@ -409,3 +409,31 @@ def test_two_dms_match_reference_and_oracle(golden_dir):
             assert abs(float(sr[0]) - o_sr) < tol
         assert float(torch.abs(env.dm.coefs if torch.is_tensor(env.dm.coefs) else torch.as_tensor(env.dm.coefs)).max()) > 0
         env.close()
+
+
+def test_long_closed_loop_tracks_the_oracle():
+    """300 closed-loop steps (about 100 ring extrusions, every one drawing from the MT19937 stream) of the float32 fused
+    step kernel against the float64 oracle: the loop is contractive, so the float32 error stays at its one-step level."""
+    from oracle import ao_oracle as O                       # checker only
+    from rlao_amd.env import BatchedAOEnv
+    env = BatchedAOEnv(n_envs=2, device=0, dtype="f32")
+    env.set_params(dict(SMALL, nLoop=400), wfs_type="shackhartmann")
+    ref = O.OracleEnv(resolution=48, diameter=3.2, n_subap=8, r0=0.13, L0=30.0, windSpeed=[10.0], windDirection=[72.0],
+                      fractionalR0=[1.0], altitude=[0.0], m2c=env.M2C_CL, n_modes=20, nLoop=400)
+    env.generate_new_phase_screen(29)
+    env.dm.coefs = 0
+    env.measure()
+    obs = env.reset_soft()
+    ref.new_episode(29)
+    o_obs = ref.reset_soft()
+    worst = 0.0
+    for i in range(300):
+        act = (0.5 * obs).float()
+        obs, frame, rew, sr, done, info = env.step(i, act)
+        o_obs, _, o_rew, o_sr, _, _ = ref.step(i, act[0].cpu().numpy())
+        worst = max(worst, float(np.abs(obs[0].cpu().numpy() - o_obs).max()))
+        assert abs(float(sr[0]) - o_sr) < 2e-5
+    assert worst < 5e-5, worst
+    np.testing.assert_allclose(env.residual[:300, 0], ref.residual[:300], atol=5e-3)
+    np.testing.assert_allclose(env.total[:300, 0], ref.total[:300], atol=5e-3)
+    env.close()
