@@ -198,10 +198,19 @@ template <typename T>
 __device__ inline void block_minmax(const T* __restrict__ map, T* __restrict__ minmax, int S, int e) {
     __shared__ T red_lo[16], red_hi[16];
     T lo = (T)3.0e38, hi = (T)-3.0e38;
-    for (int i = threadIdx.x; i < S * S; i += blockDim.x) {        // the torus is a permutation: scan physically
-        const T v = map[i];
-        lo = v < lo ? v : lo;
-        hi = v > hi ? v : hi;
+    // the torus is a permutation: scan physically, 8 independent loads per lane in flight (ELT screens: 236 k pixels per env)
+    for (int i0 = threadIdx.x; i0 < S * S; i0 += 8 * (int)blockDim.x) {
+        T v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int i = i0 + q * (int)blockDim.x;
+            v[q] = map[i < S * S ? i : i0];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            lo = v[q] < lo ? v[q] : lo;
+            hi = v[q] > hi ? v[q] : hi;
+        }
     }
     for (int off = 32; off > 0; off >>= 1) {
         const T ol = __shfl_down(lo, off), oh = __shfl_down(hi, off);

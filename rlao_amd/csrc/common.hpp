@@ -81,14 +81,27 @@ int launch_gemm_nt_mfma(const float* X, const float* W, float* Cpart, int M, int
 template <typename T>
 int launch_gemm_nt(const T* X, const T* W, T* C, int M, int N, int K, int ldx, int ldw, int ldc, hipStream_t st);
 
+// MFMA 16x16x4 operand tables.  Lane (lc = lane & 15, lq = lane >> 4) of a wave working on the 16-row tile t needs
+// g[16 t + lc][lq + 4 s] for every k step s: the table stores a lane's four consecutive steps as one float4 and the 64
+// lanes' float4s of one (tile, step quad) contiguously, so every operand load is one fully coalesced 1 KB wave access
+// (a row-major table makes the same load touch 64 cache lines, which was half of the ELT-size phase kernel).
+__host__ __device__ inline size_t ga_index(int x, int k, int ga_stride) {
+    const int q = k & 3, s = k >> 2;
+    return ((((size_t)(x >> 4) * (ga_stride >> 2) + (s >> 2)) * 4 + q) * 16 + (x & 15)) * 4 + (s & 3);
+}
 template <typename T>
 struct PhaseBuffers {
     T* opd_atm;            // [E][R*R]
     const T* coefs;        // [E][A]
+    const T* coefs_img;    // [E][nAct^2] the same as actuator images (zero elsewhere), or nullptr: the kernel scatters coefs itself
     const T* dm_opd;       // [E][R*R] (dense DM path) or nullptr
     const T* gx;           // [R][nAct]
     const T* gy;           // [R][nAct]
     const T* gxt;          // [nActPad4][Rpad128] zero-padded transpose of gx (MFMA B operand), may be null
+    const float* gxa;      // gx as float32 MFMA operands, ga_index() layout: [Rpad128 / 16][ga_stride / 4][64 lanes][4]
+    const float* gya;      // the same for gy
+    int ga_stride;         // k steps per lane (n_act / 4 rounded up to a multiple of 4)
+    const float* s1a;      // [E] x the same layout: Gy C (k_dm_rows), or nullptr: the kernel forms its rows itself
     const int* act_idx;    // [A]
     const uint8_t* pupil;  // [R*R]
     T* phase;              // [E][R*R]
@@ -96,6 +109,12 @@ struct PhaseBuffers {
     T* wfs_max;            // [E] zeroed here for the WFS kernels
 };
 int phase_tiles(int R, int n_act, size_t esz);
+// coefs [E][A] -> actuator images [E][nAct^2] (large DMs: every tile workgroup of the phase kernel would otherwise repeat the scatter)
+template <typename T>
+int launch_coefs_image(const T* coefs, const int* act_idx, T* img, int n_env, int n_act, int n_valid_act, hipStream_t st);
+// float32, separable DM: Gy C of every env in MFMA operand layout, once per step (see k_dm_rows)
+int launch_dm_rows(const float* coefs, const int* act_idx, const float* gya, float* s1a, int n_env, int R, int n_act, int n_valid_act,
+                   int ga_stride, hipStream_t st);
 template <typename T>
 struct KArgs {                 // kernel argument block of the phase kernels
     PhaseArgs pa;

@@ -41,6 +41,7 @@ struct AoEnv {
     LayerClock clk[kMaxLayer];
     int org[kMaxLayer][2] = {{0, 0}};        // torus origin (oy, ox) of every layer: logical (r, c) at ((r + oy) % S, (c + ox) % S)
     int ring_pending[kMaxLayer] = {0};       // > 0: split count of a ring extrusion whose scatter the next fused step kernel will do
+    bool use_coefs_img = false;              // aoenv_set_option(AOENV_OPT_COEFS_IMAGE); always on above 1024 actuators
     bool defer_ring = true;                  // aoenv_set_option(AOENV_OPT_DEFER_RING)
     bool minmax_dirty[kMaxLayer] = {false};  // the layer's min / max table is stale (ring extruded without the min / max pass)
     bool have[AOENV_C_COUNT] = {false};
@@ -65,6 +66,8 @@ struct AoEnv {
     uint8_t* pupil = nullptr;
     void* opd_atm = nullptr;
     void* coefs = nullptr;
+    float* dm_rows = nullptr;               // [E][Rpad128][4][ga_stride] Gy C per env (float32; k_dm_rows), the same switch
+    void* coefs_img = nullptr;              // [E][nAct^2] command images for the phase kernels of large DMs (A > 1024)
     void* phase = nullptr;
     void* scal = nullptr;                   // [E][4]
     double* part = nullptr;                 // [E][tiles][4] telemetry partial sums of the phase kernel
@@ -77,8 +80,9 @@ struct AoEnv {
     uint8_t* valid2d = nullptr;             // [nSub*nSub]
     short* slot_of = nullptr;               // [nSub*nSub] lenslet -> compact valid index, -1 = not valid
     float* amp_pupil = nullptr;             // [R*R] fused step kernel: amplitude inside the pupil, -1 outside
-    float* gxa = nullptr;                   // [128][4][8] fused step kernel: gx / gy re-laid out as MFMA operand pairs
+    float* gxa = nullptr;                   // gx / gy re-laid out as MFMA operand tables (ga_index(), common.hpp), zero padded to Rpad128
     float* gya = nullptr;
+    int ga_stride = 8;                      // k steps per (row, q), a multiple of 4 (16-byte loads), >= ceil(nAct / 4)
     std::vector<uint8_t> h_pupil;           // host copies, to rebuild amp_pupil
     std::vector<double> h_amp;
     bool amp_pupil_dirty = true;
@@ -126,7 +130,19 @@ struct AoEnv {
 
 namespace {
 
-int dmalloc(AoEnv* env, void** p, size_t bytes, bool zero = true) {
+int dmalloc(AoEnv* env, void** p, size_t bytes, bool zero = true);
+// per-env DM command products shared by the tiles of the phase kernels (AOENV_OPT_COEFS_IMAGE): float32 shards keep Gy C in
+// MFMA operand layout (k_dm_rows; its padding stays zero from here on), float64 shards the scattered command image
+static int alloc_dm_rows(AoEnv* env) {
+    if (env->esz == 4 && env->nAct <= 128) {
+        if (!env->dm_rows)
+            AO_TRY(dmalloc(env, (void**)&env->dm_rows, (size_t)env->E * (cdiv(env->R, 128) * 128) * 4 * env->ga_stride * sizeof(float)));
+    } else if (!env->coefs_img) {
+        AO_TRY(dmalloc(env, &env->coefs_img, (size_t)env->E * env->nAct * env->nAct * env->esz));
+    }
+    return 0;
+}
+int dmalloc(AoEnv* env, void** p, size_t bytes, bool zero) {
     if (bytes == 0) bytes = 16;
     AO_HIP(hipMalloc(p, bytes));
     env->allocs.push_back(*p);
@@ -306,6 +322,15 @@ void fill_phase_args(AoEnv* env, PhaseArgs& pa, PhaseBuffers<T>& pb, int update_
 template <typename T>
 int run_phase(AoEnv* env, int update_atm, int store_atm, hipStream_t st, int store_phase = 1) {
     AO_TRY(refresh_minmax<T>(env, st));
+    if (env->use_coefs_img && env->c.dm_separable) {               // ELT-size DMs: once per env instead of once per tile
+        if constexpr (std::is_same<T, float>::value) {
+            if (env->dm_rows)                                       // Gy C on the matrix cores, in operand layout
+                AO_TRY(launch_dm_rows(env->as<float>(env->coefs), env->act_idx, env->gya, env->dm_rows, env->E, env->R, env->nAct, env->A,
+                                      env->ga_stride, st));
+        }
+        if (env->coefs_img)
+            AO_TRY(launch_coefs_image<T>(env->as<T>(env->coefs), env->act_idx, env->as<T>(env->coefs_img), env->E, env->nAct, env->A, st));
+    }
     PhaseArgs pa;
     PhaseBuffers<T> pb;
     fill_phase_args<T>(env, pa, pb, update_atm, store_atm, store_phase);
@@ -472,10 +497,15 @@ void fill_phase_args(AoEnv* env, PhaseArgs& pa, PhaseBuffers<T>& pb, int update_
     pb = PhaseBuffers<T>{};
     pb.opd_atm = env->as<T>(env->opd_atm);
     pb.coefs = env->as<T>(env->coefs);
+    pb.coefs_img = env->use_coefs_img && env->coefs_img ? env->as<T>(env->coefs_img) : nullptr;
+    pb.s1a = env->use_coefs_img && env->c.dm_separable ? env->dm_rows : nullptr;
     pb.dm_opd = env->c.dm_separable ? nullptr : env->as<T>(env->dm_opd);
     pb.gx = env->as<T>(env->gx);
     pb.gy = env->as<T>(env->gy);
     pb.gxt = env->as<T>(env->gxt);
+    pb.gxa = env->gxa;
+    pb.gya = env->gya;
+    pb.ga_stride = env->ga_stride;
     pb.act_idx = env->act_idx;
     pb.pupil = env->pupil;
     pb.phase = env->as<T>(env->phase);
@@ -703,8 +733,10 @@ int aoenv_create(const AoCfg* cfg, int device, AoEnv** out) {
     A_((void**)&e->valid2d, (size_t)e->nSub * e->nSub);
     A_((void**)&e->slot_of, (size_t)e->nSub * e->nSub * sizeof(short));
     A_((void**)&e->amp_pupil, R2 * sizeof(float));
-    A_((void**)&e->gxa, (size_t)128 * 32 * sizeof(float));
-    A_((void**)&e->gya, (size_t)128 * 32 * sizeof(float));
+    e->ga_stride = std::max(8, ((cdiv(e->nAct, 4) + 3) / 4) * 4);
+    A_((void**)&e->gxa, (size_t)(cdiv(e->R, 128) * 128) * 4 * e->ga_stride * sizeof(float));
+    A_((void**)&e->gya, (size_t)(cdiv(e->R, 128) * 128) * 4 * e->ga_stride * sizeof(float));
+    if (e->A > 1024 && !rc) { rc = alloc_dm_rows(e); e->use_coefs_img = true; }
     A_(&e->sh_ref, (size_t)2 * e->nVal * z);
     A_(&e->tw, (size_t)e->n * 2 * z);
     A_(&e->phs, (size_t)e->p * 2 * z);
@@ -808,10 +840,11 @@ int aoenv_upload(AoEnv* env, int kind, const void* h, size_t bytes) {
         case AOENV_C_DM_GY:
             AO_TRY(need((size_t)env->R * env->nAct * 8));
             AO_TRY(upload_real(env, kind == AOENV_C_DM_GX ? env->gx : env->gy, d, (size_t)env->R * env->nAct));
-            if (env->R <= 128 && env->nAct <= 32) {                  // operand layout of the fused step kernel
-                std::vector<float> t((size_t)128 * 32, 0.f);
+            {                                                      // MFMA operand layout (float32 kernels): zero padded
+                const int st_ = env->ga_stride;
+                std::vector<float> t((size_t)(cdiv(env->R, 128) * 128) * 4 * st_, 0.f);
                 for (int x = 0; x < env->R; ++x)
-                    for (int k = 0; k < env->nAct; ++k) t[((size_t)x * 4 + (k & 3)) * 8 + (k >> 2)] = (float)d[(size_t)x * env->nAct + k];
+                    for (int k = 0; k < env->nAct; ++k) t[ga_index(x, k, st_)] = (float)d[(size_t)x * env->nAct + k];
                 AO_HIP(hipMemcpy(kind == AOENV_C_DM_GX ? env->gxa : env->gya, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
             }
             if (kind == AOENV_C_DM_GX) {
@@ -1369,6 +1402,10 @@ int aoenv_set_option(AoEnv* env, int option, int value) {
         case AOENV_OPT_FUSED_TAIL: env->use_fused_tail = value != 0; return 0;
         case AOENV_OPT_FUSED_STEP: env->use_fused_step = value != 0; return 0;
         case AOENV_OPT_DEFER_RING: env->defer_ring = value != 0; return 0;
+        case AOENV_OPT_COEFS_IMAGE:
+            if (value) AO_TRY(alloc_dm_rows(env));
+            env->use_coefs_img = value != 0;
+            return 0;
         case 99: env->debug_ablate = value; return 0;
         default: return fail("unknown option %d", option);
     }

@@ -166,10 +166,10 @@ int launch_gemm_nt_mfma(const float* X, const float* W, float* Cpart, int M, int
 // image is consumed before it is overwritten.
 // ---------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void __launch_bounds__(256) k_recon_finish(const FinishArgs<T> f) {
+__global__ void __launch_bounds__(1024) k_recon_finish(const FinishArgs<T> f) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     T* img_s = reinterpret_cast<T*>(lds_raw);          // the full image, zero at non-actuators (vec_to_img)
-    __shared__ double red[4];
+    __shared__ double red[16];
     const int e = blockIdx.x, n_env = gridDim.x;
     const int img = f.n_act * f.n_act;
     T* ob = f.obs + (size_t)e * img;
@@ -202,8 +202,10 @@ __global__ void __launch_bounds__(256) k_recon_finish(const FinishArgs<T> f) {
     if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x / kWave] = ss;
     __syncthreads();
     if (threadIdx.x == 0) {
-        if (f.reward) f.reward[e] = (T)(-sqrt(red[0] + red[1] + red[2] + red[3]));
-        if (f.ret && f.do_integrate) f.ret[e] += (T)(-sqrt(red[0] + red[1] + red[2] + red[3]));
+        double tot = 0;
+        for (int q = 0; q < (int)blockDim.x / kWave; ++q) tot += red[q];
+        if (f.reward) f.reward[e] = (T)(-sqrt(tot));
+        if (f.ret && f.do_integrate) f.ret[e] += (T)(-sqrt(tot));
         // telemetry from the phase kernel's per-tile sums (fixed order): std(OPD[pupil]) * 1e9, exp(-var(phase[pupil]))
         double v[4] = {0, 0, 0, 0};
         const double* pp = f.part + (size_t)e * f.n_tiles * 4;
@@ -231,7 +233,9 @@ __global__ void __launch_bounds__(256) k_recon_finish(const FinishArgs<T> f) {
 
 template <typename T>
 int launch_recon_finish(const FinishArgs<T>& fa, int n_env, hipStream_t st) {
-    hipLaunchKernelGGL(k_recon_finish<T>, dim3(n_env), dim3(256), (size_t)fa.n_act * fa.n_act * sizeof(T), st, fa);
+    // one workgroup per env; ELT-size DMs (thousands of actuators, each a short chain of dependent loads) get 1024 lanes
+    hipLaunchKernelGGL(k_recon_finish<T>, dim3(n_env), dim3(fa.n_valid_act > 1024 ? 1024 : 256),
+                       (size_t)fa.n_act * fa.n_act * sizeof(T), st, fa);
     AO_HIP(hipGetLastError());
     return 0;
 }

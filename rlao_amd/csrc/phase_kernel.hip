@@ -52,10 +52,15 @@ __global__ void __launch_bounds__(256) k_phase(const KArgs<T> a) {
     if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && a.pa.store_phase) a.pb.wfs_max[e] = (T)0;
 
     if (separable) {
-        for (int i = tid; i < nA * nA; i += 256) cimg[i] = (T)0;
-        __syncthreads();
-        const T* cf = a.pb.coefs + (size_t)e * a.n_valid_act;
-        for (int k = tid; k < a.n_valid_act; k += 256) cimg[a.pb.act_idx[k]] = cf[k];
+        if (a.pb.coefs_img) {
+            const T* ci = a.pb.coefs_img + (size_t)e * nA * nA;
+            for (int i = tid; i < nA * nA; i += 256) cimg[i] = ci[i];
+        } else {
+            for (int i = tid; i < nA * nA; i += 256) cimg[i] = (T)0;
+            __syncthreads();
+            const T* cf = a.pb.coefs + (size_t)e * a.n_valid_act;
+            for (int k = tid; k < a.n_valid_act; k += 256) cimg[a.pb.act_idx[k]] = cf[k];
+        }
         // Gx^T of this tile's columns (global reads run along ix then x: contiguous)
         for (int i = tid; i < txe * nA; i += 256) {
             const int x = i / nA, ix = i - x * nA;
@@ -152,7 +157,7 @@ __global__ void __launch_bounds__(256) k_phase(const KArgs<T> a) {
                 }
                 const bool in = a.pb.pupil[q] != 0;
                 const T res = in ? (atm + dm) : (T)0;
-                if (a.pa.store_phase) a.pb.phase[pix0 + q] = res * a.src_scale;
+                if (a.pa.store_phase && (!(a.ablate & 8) || res == 12345.f)) a.pb.phase[pix0 + q] = res * a.src_scale;
                 if (in) {
                     const double da = (double)atm, dr = (double)res;
                     s_atm += da;
@@ -191,14 +196,52 @@ __global__ void __launch_bounds__(256) k_phase(const KArgs<T> a) {
 // ---------------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// s1 tile rows on the matrix cores (see k_phase_mfma).  KS = k steps held in registers (n_act <= 4 KS).  Every load is
+// unconditional from a clamped index: a predicated load compiles to a branch, and a run of them to a chain of latencies.
+template <int KS>
+__device__ inline void s1_tiles_mfma(const float* __restrict__ gya, int ga_stride, const float* cimg, float* s1, int y0, int R,
+                                     int nA, int nAp, int SS, int lc, int lq, int wave) {
+    float av[KS];
+    const int yrow = y0 + lc;                                // < Rpad128: the table is zero padded beyond R and n_act
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(gya) + (size_t)(y0 >> 4) * (ga_stride >> 2) * 64 + (lq * 16 + lc);
+#pragma unroll
+        for (int q4 = 0; q4 < KS / 4; ++q4) {
+            const f32x4 t = src[4 * q4 < ga_stride ? 64 * q4 : 0];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) av[4 * q4 + d] = 4 * q4 < ga_stride ? t[d] : 0.f;     // A[i = lane & 15 -> row][k = lane >> 4]
+        }
+    }
+    for (int ct = wave; 16 * ct < nA; ct += 4) {
+        const int ix = 16 * ct + lc;
+        float bv[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int iy = lq + 4 * ks;
+            const bool ok = iy < nA && ix < nA;
+            const float t = cimg[ok ? iy * nA + ix : 0];
+            bv[ks] = ok ? t : 0.f;                           // B[k = lane >> 4][j = lane & 15]
+        }
+        f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            if (4 * ks < nAp) d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bv[ks], d, 0, 0, 0);
+        if (ix < nA) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s1[(4 * lq + r) * SS + ix] = d[r];
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) k_phase_mfma(const KArgs<float> a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int R = a.R, nA = a.n_act, S = a.pa.S;
     constexpr int TX = kTXmax, MW = TX + 4;
     const int nAp = (nA + 3) & ~3, SS = nAp + 1;             // K padded to 4, s1 row stride odd (bank spread)
+    const bool rows_given = a.pb.s1a != nullptr;             // Gy C already in HBM (k_dm_rows): no command image, no s1 here
     float* cimg = reinterpret_cast<float*>(lds_raw);         // [nA][nA]
     float* s1 = cimg + nA * nA;                              // [16][SS]
-    float* mapt = s1 + kTY * SS;                             // [kTY + 3][MW]
+    float* mapt = rows_given ? cimg : s1 + kTY * SS;         // [kTY + 3][MW]
     __shared__ double red[4][4];
 
     const int e = blockIdx.z;
@@ -210,41 +253,33 @@ __global__ void __launch_bounds__(256) k_phase_mfma(const KArgs<float> a) {
 
     if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && a.pa.store_phase) a.pb.wfs_max[e] = 0.f;
 
-    for (int i = tid; i < nA * nA; i += 256) cimg[i] = 0.f;
-    for (int i = tid; i < kTY * SS; i += 256) s1[i] = 0.f;
-    __syncthreads();
-    {
+    if (rows_given) {
+    } else if (a.pb.coefs_img) {
+        for (int i = tid; i < kTY * SS; i += 256) s1[i] = 0.f;
+        // batches of 8 independent loads per lane (a load-then-store loop pays one memory latency per iteration)
+        const float* ci = a.pb.coefs_img + (size_t)e * nA * nA;
+        for (int i0 = tid; i0 < nA * nA; i0 += 8 * 256) {
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = ci[i0 + 256 * q < nA * nA ? i0 + 256 * q : i0];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) if (i0 + 256 * q < nA * nA) cimg[i0 + 256 * q] = v[q];
+        }
+    } else {
+        for (int i = tid; i < kTY * SS; i += 256) s1[i] = 0.f;
+        for (int i = tid; i < nA * nA; i += 256) cimg[i] = 0.f;
+        __syncthreads();
         const float* cf = a.pb.coefs + (size_t)e * a.n_valid_act;
         for (int k = tid; k < a.n_valid_act; k += 256) cimg[a.pb.act_idx[k]] = cf[k];
     }
     __syncthreads();
-    // s1[y][ix] = sum_iy gy[y0 + y][iy] C[iy][ix].  The tile's rows of gy are staged in LDS first (one batch
-    // of independent loads): a per-iteration global load inside the dot product serialises 21 memory latencies.
-    if (!(a.ablate & 1)) {
-        float* gyt = mapt;                                   // [kTY][nA], the layer tile is not loaded yet
-        {
-            const float* g0 = a.pb.gy + (size_t)y0 * nA;
-            const int cnt = tye * nA;                        // contiguous rows
-            float v[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = (tid + 256 * k < cnt) ? g0[tid + 256 * k] : 0.f;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) if (tid + 256 * k < cnt) gyt[tid + 256 * k] = v[k];
-            for (int i = tid + 1024; i < cnt; i += 256) gyt[i] = g0[i];
-        }
-        __syncthreads();
-        for (int i = tid; i < kTY * 32; i += 256) {
-            const int y = i >> 5;
-            for (int ix = i & 31; ix < nA; ix += 32) {
-                if (y < tye) {
-                    const float* g = gyt + y * nA;
-                    float acc = 0.f;
-#pragma unroll 8
-                    for (int iy = 0; iy < nA; ++iy) acc = fmaf(g[iy], cimg[iy * nA + ix], acc);
-                    s1[y * SS + ix] = acc;
-                }
-            }
-        }
+    // s1[y][ix] = sum_iy gy[y0 + y][iy] C[iy][ix] on the matrix cores: 16 x 16 output tiles over the command columns,
+    // wave w takes the tiles w, w + 4, ...; the A operands (the tile's 16 rows of gy) are the same for every column tile
+    // and are loaded once, all loads in flight together.  (As a per-output dot product through LDS this was 2/3 of the
+    // kernel at 81 actuators across: a chain of nA LDS latencies per output.)
+    if (!rows_given && !(a.ablate & 1)) {
+        if (nAp <= 32) s1_tiles_mfma<8>(a.pb.gya, a.pb.ga_stride, cimg, s1, y0, R, nA, nAp, SS, lc, lq, ly);
+        else s1_tiles_mfma<32>(a.pb.gya, a.pb.ga_stride, cimg, s1, y0, R, nA, nAp, SS, lc, lq, ly);
     }
 
     // lane's pixels: sub-tile tt (x = 16 (2 ly + tt) + lc), rows y = 4 lq + r
@@ -271,8 +306,9 @@ __global__ void __launch_bounds__(256) k_phase_mfma(const KArgs<float> a) {
                     int pr = rr + tp.oy, pc = cc + tp.ox;           // torus: physical = (logical + origin) mod S
                     pr = pr >= S ? pr - S : pr;
                     pc = pc >= S ? pc - S : pc;
-                    v[k] = (idx < (kTY + 3) * MW && r < tye + 3 && c < txe + 3 && rr >= 0 && rr < S && cc >= 0 && cc < S)
-                               ? map[(size_t)pr * S + pc] : 0.f;
+                    const bool okl = idx < (kTY + 3) * MW && r < tye + 3 && c < txe + 3 && rr >= 0 && rr < S && cc >= 0 && cc < S;
+                    const float t = map[okl ? (size_t)pr * S + pc : 0];       // unconditional load from a clamped index
+                    v[k] = okl ? t : 0.f;
                 }
 #pragma unroll
                 for (int k = 0; k < NV; ++k) {
@@ -307,16 +343,57 @@ __global__ void __launch_bounds__(256) k_phase_mfma(const KArgs<float> a) {
     }
     __syncthreads();                                              // s1 complete
 
+    // the pupil flags of the lane's 8 pixels, all loads issued together (a conditional load per pixel is a latency each)
+    bool pup[2][4];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int xl = 16 * (2 * ly + tt) + lc, y = 4 * lq + r;
+            const bool okp = xl < txe && y < tye;
+            const uint8_t t = (a.ablate & 64) ? 1 : a.pb.pupil[okp ? (size_t)(y0 + y) * R + (x0 + xl) : 0];
+            pup[tt][r] = okp && t != 0;
+        }
     double s_atm = 0.0, q_atm = 0.0, s_res = 0.0, q_res = 0.0;
+    // A[i = lane & 15 -> tile row][k = lane >> 4 + 4 s] = (Gy C)[y0 + i][k] from the operand-layout rows k_dm_rows wrote:
+    // ga_stride / 4 16-byte loads per lane (<= 8: n_act <= 128), all in flight together
+    constexpr int NQ = 8;
+    f32x4 aq[NQ];
+    const int nq = a.pb.ga_stride / 4;
+    if (rows_given && !(a.ablate & 4)) {
+        const int Rp = (R + 127) & ~127;
+        const f32x4* asrc = reinterpret_cast<const f32x4*>(a.pb.s1a) + ((size_t)e * (Rp >> 4) + (y0 >> 4)) * nq * 64 + lx;
+#pragma unroll
+        for (int q4 = 0; q4 < NQ; ++q4) aq[q4] = asrc[q4 < nq ? 64 * q4 : 0];
+    }
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
         const int xl = 16 * (2 * ly + tt) + lc;
         f32x4 dmv = {0.f, 0.f, 0.f, 0.f};
         const float* ap = s1 + lc * SS + lq;                      // A[i = lane & 15][k = lane >> 4]            (LDS)
-        const float* bp = a.pb.gxt + (size_t)lq * a.rp + x0 + xl;  // B[k = lane >> 4][j = lane & 15]  (global, L1/L2)
-        if (!(a.ablate & 4))
-        for (int kk = 0; kk < nAp; kk += 4)
-            dmv = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[kk], bp[(size_t)kk * a.rp], dmv, 0, 0, 0);
+        // B[k = lane >> 4 + 4 s][j = lane & 15 -> column] = gx[x][k]: the operand table gives a lane its k steps as 16-byte loads
+        const f32x4* bsrc = reinterpret_cast<const f32x4*>(a.pb.gxa) + (size_t)((x0 >> 4) + 2 * ly + tt) * nq * 64 + lx;
+        if (rows_given) {
+            if (!(a.ablate & 4)) {
+            f32x4 bq[NQ];
+#pragma unroll
+            for (int q4 = 0; q4 < NQ; ++q4) bq[q4] = bsrc[q4 < nq ? 64 * q4 : 0];
+#pragma unroll
+            for (int q4 = 0; q4 < NQ; ++q4)
+                if (16 * q4 < nAp) {                              // uniform
+#pragma unroll
+                    for (int d = 0; d < 4; ++d)
+                        if (16 * q4 + 4 * d < nAp) dmv = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[q4][d], bq[q4][d], dmv, 0, 0, 0);
+                }
+            }
+        } else if (!(a.ablate & 4))
+        for (int kb = 0; kb < nAp; kb += 32) {                    // 8 k steps = 2 loads per batch
+            const f32x4 b0 = bsrc[64 * (kb / 16)], b1 = bsrc[64 * (kb / 16 + 1 < nq ? kb / 16 + 1 : kb / 16)];
+            const float bv[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (kb + 4 * j < nAp) dmv = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[kb + 4 * j], bv[j], dmv, 0, 0, 0);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int y = 4 * lq + r;
@@ -329,9 +406,9 @@ __global__ void __launch_bounds__(256) k_phase_mfma(const KArgs<float> a) {
                 } else {
                     atm = a.pb.opd_atm[pix0 + q];
                 }
-                const bool in = (a.ablate & 16) ? true : a.pb.pupil[q] != 0;
+                const bool in = (a.ablate & 16) ? true : pup[tt][r];
                 const float res = in ? (atm + dmv[r]) : 0.f;
-                if (a.pa.store_phase) a.pb.phase[pix0 + q] = res * a.src_scale;
+                if (a.pa.store_phase && (!(a.ablate & 8) || res == 12345.f)) a.pb.phase[pix0 + q] = res * a.src_scale;
                 if (in && !(a.ablate & 32)) {
                     const double da = (double)atm, dr = (double)res;
                     s_atm += da;
@@ -364,8 +441,8 @@ int launch_phase_mfma(const KArgs<T>&, int, hipStream_t) { return -1; }
 template <>
 int launch_phase_mfma<float>(const KArgs<float>& a, int n_env, hipStream_t st) {
     const int nA = a.n_act, nAp = (nA + 3) & ~3, TX = kTXmax, MW = TX + 4;
-    const size_t lds = sizeof(float) * ((size_t)nA * nA + (size_t)kTY * (nAp + 1) + (size_t)(kTY + 3) * MW);
-    if (a.pb.gxt == nullptr) return -1;
+    const size_t lds = sizeof(float) * ((a.pb.s1a ? 0 : (size_t)nA * nA + (size_t)kTY * (nAp + 1)) + (size_t)(kTY + 3) * MW);
+    if (a.pb.gxa == nullptr || nA > 128) return -1;
     if (lds > 160 * 1024) return -1;
     if (lds > 64 * 1024)
         AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_phase_mfma), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -382,6 +459,104 @@ static size_t phase_lds_bytes(int n_act, int tx, size_t esz) {
     const int MW = tx + 4;
     return esz * ((size_t)n_act * n_act + (size_t)kTY * n_act + (size_t)n_act * tx + (size_t)(kTY + 3) * MW + (size_t)(kTY + 3) * tx);
 }
+template <typename T>
+__global__ void __launch_bounds__(256) k_coefs_image(const T* __restrict__ coefs, const int* __restrict__ act_idx, T* __restrict__ img,
+                                                     int n_act, int n_valid_act) {
+    const int e = blockIdx.y;
+    T* im = img + (size_t)e * n_act * n_act;
+    // grid.x workgroups share the image: zero first (its own slice), then scatter -- the scatter targets are disjoint from
+    // every zero store of a valid actuator only within ONE workgroup, so one workgroup per env does both
+    for (int i = threadIdx.x; i < n_act * n_act; i += blockDim.x) im[i] = (T)0;
+    __syncthreads();
+    const T* cf = coefs + (size_t)e * n_valid_act;
+    for (int k = threadIdx.x; k < n_valid_act; k += blockDim.x) im[act_idx[k]] = cf[k];
+}
+// Gy C for every pixel row of every env, once per step (float32, separable DM): s1[e][y][k] = sum_iy gy[y][iy] C_e[iy][k], stored in
+// the MFMA operand layout (ga_index(), common.hpp) that k_phase_mfma reads with coalesced 16-byte loads.  Each 16 x 128 tile workgroup
+// of the phase kernel used to rebuild the command image (n_act^2 floats of LDS) and its 16 rows of this product: at 81
+// actuators across that was a third of the kernel, 30 x 4 times per env.  Workgroup = (128-row band, env): the command image
+// is scattered into LDS once, wave w takes the row tiles w and w + 4, all column tiles.
+template <int KS>
+__global__ void __launch_bounds__(256) k_dm_rows(const float* __restrict__ coefs, const int* __restrict__ act_idx,
+                                                 const float* __restrict__ gya, float* __restrict__ s1a, int R, int nA,
+                                                 int n_valid_act, int ga_stride) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    float* cimg = reinterpret_cast<float*>(lds_raw);         // [nA][nA]
+    const int e = blockIdx.y, y0 = 128 * blockIdx.x, Rp = 128 * gridDim.x;
+    const int tid = threadIdx.x, lx = tid & 63, wave = tid >> 6, lc = lx & 15, lq = lx >> 4;
+    const int nAp = (nA + 3) & ~3;
+    for (int i = tid; i < nA * nA; i += 256) cimg[i] = 0.f;
+    __syncthreads();
+    {
+        const float* cf = coefs + (size_t)e * n_valid_act;
+        for (int k0 = tid; k0 < n_valid_act; k0 += 4 * 256) {            // 4 independent (index, value) pairs in flight
+            int ix[4];
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = k0 + 256 * q < n_valid_act ? k0 + 256 * q : k0;
+                ix[q] = act_idx[k];
+                v[q] = cf[k];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (k0 + 256 * q < n_valid_act) cimg[ix[q]] = v[q];
+        }
+    }
+    __syncthreads();
+    for (int rt = wave; rt < 8; rt += 4) {
+        float av[KS];
+        const f32x4* src = reinterpret_cast<const f32x4*>(gya) + (size_t)((y0 >> 4) + rt) * (ga_stride >> 2) * 64 + lx;
+#pragma unroll
+        for (int q4 = 0; q4 < KS / 4; ++q4) {
+            const f32x4 t = src[4 * q4 < ga_stride ? 64 * q4 : 0];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) av[4 * q4 + d] = 4 * q4 < ga_stride ? t[d] : 0.f;     // A[i = lane & 15 -> row][k = lane >> 4]
+        }
+        for (int ct = 0; 16 * ct < nAp; ++ct) {
+            const int ix = 16 * ct + lc;
+            float bv[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int iy = lq + 4 * ks;
+                const bool ok = iy < nA && ix < nA;
+                const float t = cimg[ok ? iy * nA + ix : 0];
+                bv[ks] = ok ? t : 0.f;                           // B[k = lane >> 4][j = lane & 15]
+            }
+            f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                if (4 * ks < nAp) d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bv[ks], d, 0, 0, 0);
+            if (ix < nAp) {                                      // d[r] = s1[y0 + 16 rt + 4 lq + r][ix]; rows >= R are zero (gya is)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    s1a[(size_t)e * Rp * 4 * ga_stride + ga_index(y0 + 16 * rt + 4 * lq + r, ix, ga_stride)] = d[r];
+            }
+        }
+    }
+}
+int launch_dm_rows(const float* coefs, const int* act_idx, const float* gya, float* s1a, int n_env, int R, int n_act, int n_valid_act,
+                   int ga_stride, hipStream_t st) {
+    const size_t lds = sizeof(float) * (size_t)n_act * n_act;
+    dim3 grid(cdiv(R, 128), n_env);
+    if (n_act <= 32)
+        hipLaunchKernelGGL(k_dm_rows<8>, grid, dim3(256), lds, st, coefs, act_idx, gya, s1a, R, n_act, n_valid_act, ga_stride);
+    else if (n_act <= 128)
+        hipLaunchKernelGGL(k_dm_rows<32>, grid, dim3(256), lds, st, coefs, act_idx, gya, s1a, R, n_act, n_valid_act, ga_stride);
+    else
+        return -1;
+    AO_HIP(hipGetLastError());
+    return 0;
+}
+
+template <typename T>
+int launch_coefs_image(const T* coefs, const int* act_idx, T* img, int n_env, int n_act, int n_valid_act, hipStream_t st) {
+    hipLaunchKernelGGL(k_coefs_image<T>, dim3(1, n_env), dim3(256), 0, st, coefs, act_idx, img, n_act, n_valid_act);
+    AO_HIP(hipGetLastError());
+    return 0;
+}
+template int launch_coefs_image<float>(const float*, const int*, float*, int, int, int, hipStream_t);
+template int launch_coefs_image<double>(const double*, const int*, double*, int, int, int, hipStream_t);
+
 int phase_tx(int R, int n_act, size_t esz) {
     int tx = R < kTXmax ? R : kTXmax;
     while (tx > 16 && phase_lds_bytes(n_act, tx, esz) > 160 * 1024) tx = (tx + 1) / 2;

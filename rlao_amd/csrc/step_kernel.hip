@@ -110,19 +110,19 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
     // (the barriers are compiler fences for memory operations: a load written after one is issued after it)
     // A operands of the DM product, Gx[x][k = lane >> 4 + 4 step]: the lane's two column tiles are the same in every
     // pass, so they are loaded once, long before the matrix cores need them.  The host re-lays the influence factors
-    // out as ga[x][lane >> 4][step] (8 floats per entry), so a lane's 6..8 values are two 16-byte loads, not 6..8 dwords.
+    // out as operand tables (ga_index(), common.hpp): a lane's 6..8 values are two coalesced 16-byte loads, not 6..8 dwords.
     f32x4s gx_raw[2][2], gy_raw[2];
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
-        const f32x4s* src = reinterpret_cast<const f32x4s*>(a.gxa + ((size_t)(16 * (2 * cg + tt) + lc) * 4 + lq) * 8);
+        const f32x4s* src = reinterpret_cast<const f32x4s*>(a.gxa) + (2 * cg + tt) * 2 * 64 + (tid & 63);   // ga_index(), stride 8
         gx_raw[tt][0] = src[0];
-        gx_raw[tt][1] = src[1];
+        gx_raw[tt][1] = src[64];
     }
     const int rt = w >> 1, ct = w & 1;                           // s1 tile of this wave: rows 16 rt.., command columns 16 ct..
     {
-        const f32x4s* src = reinterpret_cast<const f32x4s*>(a.gya + ((size_t)(16 * rt + lc) * 4 + lq) * 8);   // gy[row][lq + 4 step]
+        const f32x4s* src = reinterpret_cast<const f32x4s*>(a.gya) + rt * 2 * 64 + (tid & 63);   // gy[16 rt + lc][lq + 4 step]
         gy_raw[0] = src[0];
-        gy_raw[1] = src[1];
+        gy_raw[1] = src[64];
     }
     float mm_pre[kMaxLayer];                                     // stored range of every layer's screen (lane & 1: min / max)
 #pragma unroll

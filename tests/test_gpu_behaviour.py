@@ -34,7 +34,8 @@ def test_switches_agree_small():
     from rlao_amd import _lib as L
     from rlao_amd.env import BatchedAOEnv
     ref = None
-    for opts in [dict(), {L.OPT_DEFER_RING: 0}, {L.OPT_FUSED_STEP: 0}, {L.OPT_FUSED_STEP: 0, L.OPT_FAST_TRIG: 0}, {L.OPT_FAST_WFS: 0}, {L.OPT_MFMA_GEMM: 0}, {L.OPT_FAST_TRIG: 0}, {L.OPT_FUSED_TAIL: 0},
+    for opts in [dict(), {L.OPT_DEFER_RING: 0}, {L.OPT_FUSED_STEP: 0}, {L.OPT_FUSED_STEP: 0, L.OPT_COEFS_IMAGE: 1},
+                 {L.OPT_FUSED_STEP: 0, L.OPT_COEFS_IMAGE: 1, L.OPT_MFMA_GEMM: 0}, {L.OPT_FUSED_STEP: 0, L.OPT_FAST_TRIG: 0}, {L.OPT_FAST_WFS: 0}, {L.OPT_MFMA_GEMM: 0}, {L.OPT_FAST_TRIG: 0}, {L.OPT_FUSED_TAIL: 0},
                  {L.OPT_FUSED_TAIL: 0, L.OPT_MFMA_GEMM: 0},
                  {L.OPT_FAST_WFS: 0, L.OPT_MFMA_GEMM: 0, L.OPT_FAST_TRIG: 0, L.OPT_FUSED_TAIL: 0}]:
         env = BatchedAOEnv(n_envs=3, device=0, dtype="f32")
