@@ -94,20 +94,24 @@ __global__ void __launch_bounds__(256) k_gemm_nt_mfma(const float* __restrict__ 
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     const bool vec_ok = ((ldx | ldw) & 3) == 0;            // rows 16-byte aligned -> float4 staging loads
 
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        // stage 64 x 32 of X and of W: thread t -> row t/8 (+32), k offset (t%8)*4
+    // stage 64 x 32 of X and of W: thread t -> row t/8 (+32), k offset (t%8)*4.  The next slice's global loads are issued
+    // before the matrix-core loop of the current one (register double buffer): with 2-4 waves per SIMD the HBM latency of a
+    // load -> LDS -> MFMA sequence is otherwise exposed every slice (ELT-size reconstructor: K = 10^4, 134 -> see DESIGN.md).
+    float4 xv[2], wv[2];
+    auto fetch = [&](int k0) {
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
             const int r = (threadIdx.x >> 3) + pass * 32, kq = (threadIdx.x & 7) * 4;
             const int gk = k0 + kq;
-            float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), wv = xv;
+            xv[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
+            wv[pass] = xv[pass];
             const int gm = m0 + r, gn = n0 + r;
             if (vec_ok && gk + 3 < kend) {
-                if (gm < M) xv = *reinterpret_cast<const float4*>(X + (size_t)gm * ldx + gk);
-                if (gn < N) wv = *reinterpret_cast<const float4*>(W + (size_t)gn * ldw + gk);
+                if (gm < M) xv[pass] = *reinterpret_cast<const float4*>(X + (size_t)gm * ldx + gk);
+                if (gn < N) wv[pass] = *reinterpret_cast<const float4*>(W + (size_t)gn * ldw + gk);
             } else {
-                float* xp = reinterpret_cast<float*>(&xv);
-                float* wp = reinterpret_cast<float*>(&wv);
+                float* xp = reinterpret_cast<float*>(&xv[pass]);
+                float* wp = reinterpret_cast<float*>(&wv[pass]);
                 for (int d = 0; d < 4; ++d) {
                     if (gk + d < kend) {
                         if (gm < M) xp[d] = X[(size_t)gm * ldx + gk + d];
@@ -115,12 +119,20 @@ __global__ void __launch_bounds__(256) k_gemm_nt_mfma(const float* __restrict__ 
                     }
                 }
             }
+        }
+    };
+    if (kbeg < kend) fetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int r = (threadIdx.x >> 3) + pass * 32, kq = (threadIdx.x & 7) * 4;
             float* xd = xs + r * LDT + kq;
             float* wd = ws + r * LDT + kq;
-            xd[0] = xv.x; xd[1] = xv.y; xd[2] = xv.z; xd[3] = xv.w;
-            wd[0] = wv.x; wd[1] = wv.y; wd[2] = wv.z; wd[3] = wv.w;
+            xd[0] = xv[pass].x; xd[1] = xv[pass].y; xd[2] = xv[pass].z; xd[3] = xv[pass].w;
+            wd[0] = wv[pass].x; wd[1] = wv[pass].y; wd[2] = wv[pass].z; wd[3] = wv[pass].w;
         }
         __syncthreads();
+        if (k0 + BK < kend) fetch(k0 + BK);
         const float* xa = xs + (wm + lr) * LDT + lh;
         const float* wb = ws + (wn + lr) * LDT + lh;
 #pragma unroll
@@ -142,6 +154,20 @@ __global__ void __launch_bounds__(256) k_gemm_nt_mfma(const float* __restrict__ 
 
 int gemm_splits(int M, int N, int K) {
     const int tiles = cdiv(M, 64) * cdiv(N, 64);
+    if (K > 2048) {
+        // long reductions (ELT-size reconstructor): the K range is cut so that the workgroups come in whole rounds of the
+        // 256 CUs with >= 4 resident per CU.  cost = rounds x (slice length + fixed per-workgroup part) + the slab traffic
+        // (one write and one read of M N floats per slice, in units of one k step of one round ~ 20 ns)
+        int best = 1;
+        double best_cost = 1e300;
+        for (int s = 1; s <= kMaxSplits; ++s) {
+            const int wgs = tiles * s, kslice = cdiv(cdiv(K, s), 32) * 32;
+            if (wgs < 1024 && s < kMaxSplits && tiles * (s + 1) <= 1024) continue;      // too few to hide the HBM latency
+            const double cost = (double)cdiv(wgs, 256) * (kslice + 96) + (double)s * M * N * 8.0 / 4e12 / 20e-9;
+            if (cost < best_cost) { best_cost = cost; best = s; }
+        }
+        return best;
+    }
     int s = cdiv(512, tiles);
     const int smax = K / 64 > 0 ? K / 64 : 1;
     s = s < 1 ? 1 : (s > smax ? smax : s);
@@ -170,6 +196,7 @@ __global__ void __launch_bounds__(1024) k_recon_finish(const FinishArgs<T> f) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     T* img_s = reinterpret_cast<T*>(lds_raw);          // the full image, zero at non-actuators (vec_to_img)
     __shared__ double red[16];
+    __shared__ double tel[4];
     const int e = blockIdx.x, n_env = gridDim.x;
     const int img = f.n_act * f.n_act;
     T* ob = f.obs + (size_t)e * img;
@@ -196,6 +223,21 @@ __global__ void __launch_bounds__(1024) k_recon_finish(const FinishArgs<T> f) {
         img_s[px] = o;
         ss += (double)o * (double)o;
     }
+    // per-tile telemetry sums of the phase kernel: the last wave adds them, lane t the tiles t, t + 64, ... and then a
+    // fixed shuffle tree (one lane walking 120 tiles of an ELT pupil was a chain of 480 memory latencies = 40 us)
+    double tv[4] = {0, 0, 0, 0};
+    const bool tel_wave = threadIdx.x / kWave == blockDim.x / kWave - 1;
+    if (tel_wave) {
+        const double* pp = f.part + (size_t)e * f.n_tiles * 4;
+        for (int t = threadIdx.x & (kWave - 1); t < f.n_tiles; t += kWave)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tv[k] += pp[t * 4 + k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            for (int off = 32; off > 0; off >>= 1) tv[k] += __shfl_down(tv[k], off);
+        if ((threadIdx.x & (kWave - 1)) == 0)
+            for (int k = 0; k < 4; ++k) tel[k] = tv[k];
+    }
     __syncthreads();
     for (int q = threadIdx.x; q < img; q += blockDim.x) ob[q] = img_s[q];
     for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off);
@@ -207,10 +249,7 @@ __global__ void __launch_bounds__(1024) k_recon_finish(const FinishArgs<T> f) {
         if (f.reward) f.reward[e] = (T)(-sqrt(tot));
         if (f.ret && f.do_integrate) f.ret[e] += (T)(-sqrt(tot));
         // telemetry from the phase kernel's per-tile sums (fixed order): std(OPD[pupil]) * 1e9, exp(-var(phase[pupil]))
-        double v[4] = {0, 0, 0, 0};
-        const double* pp = f.part + (size_t)e * f.n_tiles * 4;
-        for (int t = 0; t < f.n_tiles; ++t)
-            for (int k = 0; k < 4; ++k) v[k] += pp[t * 4 + k];
+        const double v[4] = {tel[0], tel[1], tel[2], tel[3]};
         const double n = (double)f.n_pupil;
         double var_atm = v[1] / n - (v[0] / n) * (v[0] / n);
         double var_res = v[3] / n - (v[2] / n) * (v[2] / n);
