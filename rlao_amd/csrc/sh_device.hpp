@@ -37,11 +37,19 @@ __device__ inline void sincos_fast(float x, float* s, float* c) {
 }
 __device__ inline void sincos_fast(double x, double* s, double* c) { sincos(x, s, c); }
 
+// max over non-negative values (their bit patterns order like unsigned integers).  The running maximum is read first (a
+// relaxed device-scope load served by L2) and the atomic is issued only by a value that would raise it: a few hundred
+// waves per env raising the same word -- 64 envs' words share two cache lines -- otherwise queue up on one L2 channel
+// (ELT-size Shack-Hartmann: 20 k atomics per frame were most of the spots kernel).  A stale read is only ever too small.
 __device__ inline void atomic_max_nonneg(float* addr, float v) {
-    atomicMax(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+    unsigned int* a = reinterpret_cast<unsigned int*>(addr);
+    const unsigned int bits = __float_as_uint(v);
+    if (bits > __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a, bits);
 }
 __device__ inline void atomic_max_nonneg(double* addr, double v) {
-    atomicMax(reinterpret_cast<unsigned long long*>(addr), (unsigned long long)__double_as_longlong(v));
+    unsigned long long* a = reinterpret_cast<unsigned long long*>(addr);
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+    if (bits > __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a, bits);
 }
 
 __device__ inline double wave_sum_f64(double v) {
@@ -71,8 +79,16 @@ __device__ constexpr int k2(int u, int a) { return (a + LO) * (13 + 2 * u); }
 // PRESCALED: the field already carries the 1/n of |FFT2(E)/n|^2 (ShackHartmann.py:539), no 1/n^2 on the intensities.
 // Every product is an fma chained into its accumulator (4 per complex multiply-add, none for twiddle components that
 // are exactly zero): ~1.1 k instructions per lane.
+// ctab: the cosine table held across the wave, lane l = cos(pi (l % 24) / 12) (cos_table_lane()): the stage-1 twiddles
+// depend on the lane (q) and are fetched with wave shuffles -- indexing the constant table is a global load, i.e. an
+// HBM-class latency in front of every lenslet's arithmetic.
+template <typename T>
+__device__ inline T cos_table_lane() { return (T)kCos[(threadIdx.x & 63) % 24]; }
+__device__ inline float lane_read(float v, int l) { return __shfl(v, l); }
+__device__ inline double lane_read(double v, int l) { return __shfl(v, l); }
+
 template <typename T, int LOW_REGS = 0, bool PRESCALED = false>
-__device__ inline void lenslet_spots(const cplx<T>* __restrict__ Ej, int q, T (&Ia)[6], T (&Ib)[6]) {
+__device__ inline void lenslet_spots(const cplx<T>* __restrict__ Ej, int q, T ctab, T (&Ia)[6], T (&Ib)[6]) {
     // the two spectral columns v = 2q + c, c = 0, 1 (and their partners v + 6) one after the other:
     // keeps only 2 x 6 complex G values live (register pressure decides the occupancy here)
 #pragma unroll 1
@@ -81,9 +97,11 @@ __device__ inline void lenslet_spots(const cplx<T>* __restrict__ Ej, int q, T (&
         T t1r[P], t1i[P];
 #pragma unroll
         for (int b = 0; b < P; ++b) {
-            const int m = ((b + LO) * (13 + 2 * (2 * q + c))) % 24;
-            t1r[b] = (T)kCos[m];
-            t1i[b] = (T)(-kCos[(m + 18) % 24]);
+            const int x = (b + LO) * (13 + 2 * (2 * q + c));         // <= 184
+            const int m = x - 24 * ((x * 171) >> 12);                // x % 24 without a division
+            const int m2 = m + 18 >= 24 ? m - 6 : m + 18;
+            t1r[b] = lane_read(ctab, m);
+            t1i[b] = -lane_read(ctab, m2);
         }
         T G0r[P], G0i[P], G1r[P], G1i[P];                      // columns v and v + 6
 #pragma unroll

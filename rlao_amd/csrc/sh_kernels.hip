@@ -133,6 +133,7 @@ __global__ void __launch_bounds__(128, 2) k_sh_spots_p6(const T* __restrict__ ph
     T* fr = frame + (size_t)e * R * R;
     const int jl = lane / HP, q = lane - jl * HP;
 
+    const T ctab = cos_table_lane<T>();
     T mx = 0;
     for (int j0 = 0; j0 < n_subap; j0 += SPW) {
         // ---- stage 0: strip of phase -> E0 in LDS (all loads of the lane issued before the first use) ---------
@@ -169,8 +170,12 @@ __global__ void __launch_bounds__(128, 2) k_sh_spots_p6(const T* __restrict__ ph
         T Ia[P], Ib[P];
 #pragma unroll
         for (int u = 0; u < P; ++u) Ia[u] = Ib[u] = (T)0;
-        if (ok) {
-            lenslet_spots<T>(Ew + jl * EST, q, Ia, Ib);
+        if (row_ok)                                                    // wave-uniform: the twiddle shuffles need every lane
+            lenslet_spots<T>(Ew + (lane < SPW * HP ? jl : 0) * EST, q, ctab, Ia, Ib);
+        if (!ok) {
+#pragma unroll
+            for (int u = 0; u < P; ++u) Ia[u] = Ib[u] = (T)0;
+        } else {
 #pragma unroll
             for (int u = 0; u < P; ++u) {
                 mx = Ia[u] > mx ? Ia[u] : mx;

@@ -111,6 +111,7 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
     // A operands of the DM product, Gx[x][k = lane >> 4 + 4 step]: the lane's two column tiles are the same in every
     // pass, so they are loaded once, long before the matrix cores need them.  The host re-lays the influence factors
     // out as operand tables (ga_index(), common.hpp): a lane's 6..8 values are two coalesced 16-byte loads, not 6..8 dwords.
+    const float ctab = fast6::cos_table_lane<float>();           // stage B twiddles, fetched by wave shuffles there
     f32x4s gx_raw[2][2], gy_raw[2];
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
@@ -434,8 +435,14 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
     for (int u = 0; u < 6; ++u) Ia[u] = Ib[u] = 0.f;
     float mx = 0.f;
     int li = 0, lj = 0;
+    if (21 * w < n_valid) {                                      // wave-uniform: the twiddle shuffles need every lane
+        fast6::lenslet_spots<float, 2, true>(E0 + (ok ? s : 0) * EST, q3, ctab, Ia, Ib);
+        if (!ok) {
+#pragma unroll
+            for (int u = 0; u < 6; ++u) Ia[u] = Ib[u] = 0.f;
+        }
+    }
     if (ok) {
-        fast6::lenslet_spots<float, 2, true>(E0 + s * EST, q3, Ia, Ib);
         const int kk = a.sc.subap_idx[s];
         li = kk / n_sub;
         lj = kk - li * n_sub;
