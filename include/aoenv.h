@@ -241,8 +241,10 @@ enum AoOption {
                                  0: the separate phase / spots / tail kernels */
     AOENV_OPT_DEFER_RING = 6, /* 1 (default): on a step where a layer crosses a pixel, the fused step kernel itself writes the new
                                  border ring of the screen (sum of the ring GEMM's slabs); 0: a separate scatter launch */
-    AOENV_OPT_COEFS_IMAGE = 7, /* 1: the separate phase kernels read the DM commands as actuator images written once per env by a small
-                                 kernel (always on above 1024 actuators: ELT-size DMs); 0 (default below): every tile scatters them */
+    AOENV_OPT_COEFS_IMAGE = 7, /* 1: the per-env part of the DM surface is formed once per step by a small kernel instead of once per
+                                 tile of the separate phase kernel: float32 shards Gy.C on the matrix cores (MFMA operand layout),
+                                 float64 shards the scattered command image (always on above 1024 actuators: ELT-size DMs);
+                                 0 (default below): every tile workgroup does it itself */
     AOENV_OPT_FAST_TRIG = 2  /* 1 (default): v_sin/v_cos after Cody-Waite reduction in the float32 SH kernel; 0: sincosf */
 };
 int aoenv_set_option(AoEnv* env, int option, int value);
