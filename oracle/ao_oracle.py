@@ -772,14 +772,14 @@ class OracleEnv:
         self.nValidAct = int(dm["validAct"].sum())
         if second_dm_nsub is not None:
             # a second DM chained behind the first, tel*dm1*dm2 (Telescope.py:533-544: every DM adds its OPD): one stacked
-            # command vector [dm1 | dm2]; the actuator "image" holds both grids, dm2 below dm1
+            # command vector [dm1 | dm2]; the actuator "image" holds both grids, dm1 top-left and dm2 bottom-right
             n1, n2 = self.nActuator, second_dm_nsub + 1
             dm2 = dm_geometry(resolution, diameter, second_dm_nsub, mech_coupling, pitch=diameter / n2)
             self.dm_modes = np.hstack([dm["modes"], dm2["modes"]])
             self.nActuator = n1 + n2
             mask = np.zeros((n1 + n2, n1 + n2), bool)
             mask[:n1, :n1] = dm["validAct"].reshape(n1, n1)
-            mask[n1:, :n2] = dm2["validAct"].reshape(n2, n2)
+            mask[n1:, n1:] = dm2["validAct"].reshape(n2, n2)
             self.dm_mask = mask
             self.xvalid, self.yvalid = np.nonzero(mask)
             self.nValidAct = int(mask.sum())

@@ -272,8 +272,10 @@ class DMTables:
 class CompositeDM:
     """Two deformable mirrors chained in the beam, ``tel*dm1*dm2*wfs`` (OOPAO/Telescope.py:533-544: every DM adds its OPD;
     with fov = 0 an altitude-conjugated DM has the ground DM's grid, DeformableMirror.py:388-389).  Presented to the library
-    as ONE dense DM: command vector [dm1 | dm2], influence matrix [modes1 | modes2], and an actuator "image" of side
-    nAct1 + nAct2 that holds dm1's grid on top and dm2's below it (columns 0 .. nAct2-1)."""
+    as ONE separable DM: command vector [dm1 | dm2], factors Gy = [gy1 | gy2], Gx = [gx1 | gx2], and an actuator "image" of
+    side nAct1 + nAct2 that holds dm1's grid in its top-left block and dm2's in the bottom-right one.  The off-diagonal blocks
+    hold no actuator, so Gy C Gx^T = gy1 C1 gx1^T + gy2 C2 gx2^T: the sum of the two mirrors' surfaces, through the same
+    kernels (fused step kernel included, nAct1 + nAct2 <= 32) as a single mirror."""
 
     def __init__(self, p: AOParams, n_subap_2: int):
         self.dm1, self.dm2 = DMTables(p), DMTables(p, n_subap=n_subap_2)
@@ -281,13 +283,14 @@ class CompositeDM:
         self.nAct = n1 + n2
         mask = np.zeros((self.nAct, self.nAct), bool)
         mask[:n1, :n1] = self.dm1.dm_mask
-        mask[n1:, :n2] = self.dm2.dm_mask
+        mask[n1:, n1:] = self.dm2.dm_mask
         self.dm_mask = mask
         self.validAct = mask.reshape(-1)
         self.act_idx = np.flatnonzero(self.validAct).astype(np.int32)
         self.nValidAct = int(self.act_idx.size)
         self.xvalid, self.yvalid = np.nonzero(mask)
-        self.gx = self.gy = None                                   # not separable as a whole
+        self.gx = np.hstack([self.dm1.gx, self.dm2.gx])
+        self.gy = np.hstack([self.dm1.gy, self.dm2.gy])
 
     def dense_modes(self) -> np.ndarray:
         return np.hstack([self.dm1.dense_modes(), self.dm2.dense_modes()])

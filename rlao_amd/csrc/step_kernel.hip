@@ -64,13 +64,16 @@ static StepLds step_lds_layout(int n_act, int n_subap, int n_valid, int n_modes)
     const int nAp = (n_act + 3) & ~3, SS = nAp + 1;
     int o = 0;
     auto take = [&](int words) { const int at = o; o += (words + 3) & ~3; return at; };
+    // the slopes and the observation image / modal coefficients of stages B-C live where Gy C (s1) was: s1 is dead once
+    // stage A is over (the barrier in front of stage B), and 32 actuators across (two chained DMs) would not fit otherwise
+    const int sl_words = (2 * n_valid + 3) & ~3, img_words = n_act * n_act + n_modes;
     L.cimg = take(n_act * n_act);
-    L.s1 = take(2 * PR * SS);
+    L.s1 = take(std::max(2 * PR * SS, sl_words + img_words));
+    L.sl = L.s1;
+    L.img = L.s1 + sl_words;
     L.mapt = take(16 * WR * WC);
     L.slot = take((n_subap * n_subap + 1) / 2);
     L.e0 = take(2 * n_valid * fast6::EST);
-    L.sl = take(2 * n_valid);
-    L.img = take(n_act * n_act + n_modes);
     L.total = o;
     return L;
 }
@@ -91,8 +94,8 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
     float* mapt = lds + L.mapt + w_ * (WR * WC);                   // [WR][WC] this wave's private layer tile
     short* slot_s = reinterpret_cast<short*>(lds + L.slot);      // [nSub^2] lenslet -> compact valid index or -1
     cplx<float>* E0 = reinterpret_cast<cplx<float>*>(lds + L.e0);    // [nValid][EST]
-    float* sl = lds + L.sl;                                      // [2 nValid] slopes
-    float* img_s = lds + L.img;                                  // [nA^2 + n_modes]
+    float* sl = lds + L.sl;                                      // [2 nValid] slopes            (aliases s1: stages B-C)
+    float* img_s = lds + L.img;                                  // [nA^2 + n_modes]             (aliases s1: stage C)
     __shared__ double red[4][16];
     __shared__ double red_tail[16];
     __shared__ float red_mx[16];
@@ -134,7 +137,6 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
     const float act_c = k.pb.coefs[(size_t)e * k.n_valid_act + (has_act ? tid : 0)];
     const short slot_v = a.slot_of[tid < n_sub * n_sub ? tid : 0];
     for (int i = tid; i < nA * nA; i += 1024) cimg[i] = 0.f;
-    for (int i = tid; i < nA * nA; i += 1024) img_s[i] = 0.f;
     for (int i = tid; i < 2 * PR * SS; i += 1024) s1[i] = 0.f;
     if (tid < n_sub * n_sub) slot_s[tid] = slot_v;
     for (int i = tid + 1024; i < n_sub * n_sub; i += 1024) slot_s[i] = a.slot_of[i];
@@ -411,7 +413,8 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
         red[2][w] = s_res;
         red[3][w] = q_res;
     }
-    lds_barrier();                                             // E0 complete, red complete
+    lds_barrier();                                             // E0 complete, red complete, s1 dead
+    for (int i = tid; i < nA * nA; i += 1024) img_s[i] = 0.f;    // (aliases s1) zero at non-actuators: vec_to_img
     AO_STAMP(14);
     AO_WSTAMP(4);
     if (tid == 1023) {                                           // an idle lane: runs beside the spots of the other waves

@@ -382,7 +382,7 @@ class BatchedAOEnv:
         """Builds the loop (MAIN/OOPAOEnv/OOPAOEnv.py:93-385).  ``wfs_type`` is "pyramid" (the reference's default,
         Papyrus) or "shackhartmann" (OOPAOEnvRazor.py:232-238).  ``second_dm=dict(nSubaperture=n)`` chains a second DM of
         that pitch behind the first (``tel*dm1*dm2*wfs``, BASELINE configs[4]): commands, observations and actions then
-        cover both mirrors (``calib.CompositeDM``: one stacked actuator image), through the dense-DM kernels."""
+        cover both mirrors (``calib.CompositeDM``: one block-diagonal actuator image, separable like a single mirror)."""
         if wfs_type in ("shackhartmann", "sh"):
             self.wfs_type = "sh"
         elif wfs_type in ("pyramid", "pyr"):
@@ -399,7 +399,7 @@ class BatchedAOEnv:
         self._atm_tables = calib.AtmosphereTables(p)
         self._dm_tables = dmt = (calib.DMTables(p) if not second_dm else
                                  calib.CompositeDM(p, int(second_dm["nSubaperture"])))
-        self._dm_separable = 0 if second_dm else 1
+        self._dm_separable = 1 if dmt.gx is not None else 0
         self.nActuator, self.nValidAct = dmt.nAct, dmt.nValidAct
         self.dm_mask = dmt.dm_mask.astype(int)
         self.xvalid, self.yvalid = dmt.xvalid, dmt.yvalid
