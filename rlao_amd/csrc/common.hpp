@@ -219,6 +219,8 @@ int launch_convert_from_f64(const double* src, T* dst, size_t n, hipStream_t st)
 template <typename T> struct cx;
 struct FftPlan {
     int n;            // transform length
+    int np;           // LDS stride between the sequences of a workgroup: n made odd, so that accesses that run ACROSS the
+                      // sequences (the column gathers / scatters of the 2-D transforms) fall in different banks
     int n_fac;        // number of stages
     int fac[12];      // radix of each stage, product = n
     unsigned magic_ns[12];   // floor(2^32 / ns) + 1 of each stage (ns = product of the earlier radices): x / ns for x < 2^16

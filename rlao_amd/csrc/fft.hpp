@@ -32,14 +32,14 @@ __device__ inline int fastdiv(int x, unsigned magic) { return (int)__umulhi((uns
 // Butterfly j of a sequence reads src[j + r m] (m = n / R), multiplies by w_{ns R}^{k r} = w_n^{k r tstep} with k = j mod ns,
 // and writes dst[(j / ns) ns R + k + q ns].  k r tstep < n for every r < R: no reduction of the twiddle index is needed.
 template <typename T, int R>
-__device__ inline void fft_stage_r(const cx<T>* __restrict__ src, cx<T>* __restrict__ dst, int n, int ns, unsigned magic_ns,
+__device__ inline void fft_stage_r(const cx<T>* __restrict__ src, cx<T>* __restrict__ dst, int n, int np, int ns, unsigned magic_ns,
                                    unsigned magic_m, int nseq, const cx<T>* __restrict__ twl, int inverse) {
     const int m = n / R;
     const int tstep = m / ns;                                   // n / (ns R)
     for (int w = threadIdx.x; w < nseq * m; w += blockDim.x) {
         const int seq = fastdiv(w, magic_m), j = w - seq * m;
         const int jd = ns == 1 ? j : fastdiv(j, magic_ns), k = j - jd * ns;
-        const cx<T>* s = src + seq * n;
+        const cx<T>* s = src + seq * np;
         cx<T> v[R];
         int ti = 0;
 #pragma unroll
@@ -69,7 +69,7 @@ __device__ inline void fft_stage_r(const cx<T>* __restrict__ src, cx<T>* __restr
                 y[q] = acc;
             }
         }
-        cx<T>* d = dst + seq * n + jd * ns * R + k;
+        cx<T>* d = dst + seq * np + jd * ns * R + k;
 #pragma unroll
         for (int q = 0; q < R; ++q) d[q * ns] = y[q];
     }
@@ -80,7 +80,7 @@ __device__ inline void fft_stage_r(const cx<T>* __restrict__ src, cx<T>* __restr
 // -- 4 H real multiply-adds per output pair instead of 4 (R - 1) per output.  (528 = 4.4.3.11: the radix-11 stage was 85 %
 // of the Pyramid's transform time as a generic O(R^2) sweep with one lane per output.)
 template <typename T, int R>
-__device__ inline void fft_stage_prime(const cx<T>* __restrict__ src, cx<T>* __restrict__ dst, int n, int ns, unsigned magic_ns,
+__device__ inline void fft_stage_prime(const cx<T>* __restrict__ src, cx<T>* __restrict__ dst, int n, int np, int ns, unsigned magic_ns,
                                        unsigned magic_m, int nseq, const cx<T>* __restrict__ twl, int inverse) {
     constexpr int H = (R - 1) / 2;
     const int m = n / R;
@@ -95,7 +95,7 @@ __device__ inline void fft_stage_prime(const cx<T>* __restrict__ src, cx<T>* __r
     for (int w = threadIdx.x; w < nseq * m; w += blockDim.x) {
         const int seq = fastdiv(w, magic_m), j = w - seq * m;
         const int jd = ns == 1 ? j : fastdiv(j, magic_ns), k = j - jd * ns;
-        const cx<T>* s = src + seq * n;
+        const cx<T>* s = src + seq * np;
         cx<T> v[R];
         int ti = 0;
 #pragma unroll
@@ -112,7 +112,7 @@ __device__ inline void fft_stage_prime(const cx<T>* __restrict__ src, cx<T>* __r
             b[r] = csub(v[r], v[R - r]);
             y0 = cadd(y0, a[r]);
         }
-        cx<T>* d = dst + seq * n + jd * ns * R + k;
+        cx<T>* d = dst + seq * np + jd * ns * R + k;
         d[0] = y0;
 #pragma unroll
         for (int q = 1; q <= H; ++q) {
@@ -136,15 +136,16 @@ __device__ inline void fft_stage_prime(const cx<T>* __restrict__ src, cx<T>* __r
 // Any other (prime) radix, two sweeps: (1) every input is multiplied in place by its stage twiddle; (2) one lane per
 // OUTPUT evaluates the length-R DFT  sum_r v[r] W_R^{q r}  with W_R^p = w_n^{p m}  (R broadcast reads from the LDS table).
 template <typename T>
-__device__ inline void fft_stage_any(cx<T>* __restrict__ src, cx<T>* __restrict__ dst, int n, int ns, unsigned magic_ns,
+__device__ inline void fft_stage_any(cx<T>* __restrict__ src, cx<T>* __restrict__ dst, int n, int np, int ns, unsigned magic_ns,
                                      unsigned magic_m, int nseq, int R, const cx<T>* __restrict__ twl, int inverse) {
     const int m = n / R;
     const int tstep = m / ns;
     for (int w = threadIdx.x; w < nseq * n; w += blockDim.x) {   // element e = j + r m of sequence seq
-        const int r = fastdiv(w, magic_m) % R, j = w - fastdiv(w, magic_m) * m;   // (w / m) = seq R + r
+        const int sr = fastdiv(w, magic_m), seq = sr / R, r = sr - seq * R, j = w - sr * m;   // (w / m) = seq R + r
         if (r > 0) {
             const int jd = ns == 1 ? j : fastdiv(j, magic_ns), k = j - jd * ns;
-            src[w] = cmul(src[w], tw_lds(twl, k * r * tstep, inverse));
+            cx<T>* x = src + seq * np + r * m + j;
+            *x = cmul(*x, tw_lds(twl, k * r * tstep, inverse));
         }
     }
     __syncthreads();
@@ -152,7 +153,7 @@ __device__ inline void fft_stage_any(cx<T>* __restrict__ src, cx<T>* __restrict_
         const int sq = fastdiv(w, magic_m), j = w - sq * m;
         const int seq = sq / R, q = sq - seq * R;
         const int jd = ns == 1 ? j : fastdiv(j, magic_ns), k = j - jd * ns;
-        const cx<T>* s = src + seq * n + j;
+        const cx<T>* s = src + seq * np + j;
         cx<T> acc = s[0];
         int qr = 0;
         for (int r = 1; r < R; ++r) {
@@ -160,7 +161,7 @@ __device__ inline void fft_stage_any(cx<T>* __restrict__ src, cx<T>* __restrict_
             qr = qr >= R ? qr - R : qr;
             acc = cadd(acc, cmul(s[r * m], tw_lds(twl, qr * m, inverse)));
         }
-        dst[seq * n + jd * ns * R + k + q * ns] = acc;
+        dst[seq * np + jd * ns * R + k + q * ns] = acc;
     }
 }
 
@@ -175,14 +176,14 @@ __device__ inline cx<T>* fft_lds(cx<T>* a, cx<T>* b, const FftPlan& pl, int nseq
         const int R = pl.fac[s];
         __syncthreads();
         switch (R) {
-            case 2: fft_stage_r<T, 2>(src, dst, pl.n, ns, pl.magic_ns[s], pl.magic_m[s], nseq, twl, inverse); break;
-            case 3: fft_stage_r<T, 3>(src, dst, pl.n, ns, pl.magic_ns[s], pl.magic_m[s], nseq, twl, inverse); break;
-            case 4: fft_stage_r<T, 4>(src, dst, pl.n, ns, pl.magic_ns[s], pl.magic_m[s], nseq, twl, inverse); break;
-            case 5: fft_stage_r<T, 5>(src, dst, pl.n, ns, pl.magic_ns[s], pl.magic_m[s], nseq, twl, inverse); break;
-            case 7: fft_stage_prime<T, 7>(src, dst, pl.n, ns, pl.magic_ns[s], pl.magic_m[s], nseq, twl, inverse); break;
-            case 11: fft_stage_prime<T, 11>(src, dst, pl.n, ns, pl.magic_ns[s], pl.magic_m[s], nseq, twl, inverse); break;
-            case 13: fft_stage_prime<T, 13>(src, dst, pl.n, ns, pl.magic_ns[s], pl.magic_m[s], nseq, twl, inverse); break;
-            default: fft_stage_any<T>(src, dst, pl.n, ns, pl.magic_ns[s], pl.magic_m[s], nseq, R, twl, inverse); break;
+            case 2: fft_stage_r<T, 2>(src, dst, pl.n, pl.np, ns, pl.magic_ns[s], pl.magic_m[s], nseq, twl, inverse); break;
+            case 3: fft_stage_r<T, 3>(src, dst, pl.n, pl.np, ns, pl.magic_ns[s], pl.magic_m[s], nseq, twl, inverse); break;
+            case 4: fft_stage_r<T, 4>(src, dst, pl.n, pl.np, ns, pl.magic_ns[s], pl.magic_m[s], nseq, twl, inverse); break;
+            case 5: fft_stage_r<T, 5>(src, dst, pl.n, pl.np, ns, pl.magic_ns[s], pl.magic_m[s], nseq, twl, inverse); break;
+            case 7: fft_stage_prime<T, 7>(src, dst, pl.n, pl.np, ns, pl.magic_ns[s], pl.magic_m[s], nseq, twl, inverse); break;
+            case 11: fft_stage_prime<T, 11>(src, dst, pl.n, pl.np, ns, pl.magic_ns[s], pl.magic_m[s], nseq, twl, inverse); break;
+            case 13: fft_stage_prime<T, 13>(src, dst, pl.n, pl.np, ns, pl.magic_ns[s], pl.magic_m[s], nseq, twl, inverse); break;
+            default: fft_stage_any<T>(src, dst, pl.n, pl.np, ns, pl.magic_ns[s], pl.magic_m[s], nseq, R, twl, inverse); break;
         }
         ns *= R;
         cx<T>* t = src;

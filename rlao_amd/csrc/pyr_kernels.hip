@@ -19,14 +19,18 @@
 
 namespace ao {
 
+// LDS budget of the two sequence buffers of an FFT workgroup: ~40 KiB keeps 3-4 workgroups (12-16 waves) on a CU, which is what
+// hides the LDS / barrier latency of the Stockham stages (at 64 KiB two workgroups = 2 waves per SIMD ran in lock-step)
+constexpr size_t kFftLdsTarget = 40 * 1024;
+
 // P1: grid = (ceil(R / RB), chunk, E)
 template <typename T>
 __global__ void __launch_bounds__(256) k_pyr_rows(const PyrArgs<T> a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    const int N = a.N, R = a.R, RB = a.seq_per_block;
+    const int N = a.N, NP = a.plan.np, R = a.R, RB = a.seq_per_block;
     cx<T>* A = reinterpret_cast<cx<T>*>(lds_raw);
-    cx<T>* B = A + RB * N;
-    cx<T>* twl = B + RB * N;
+    cx<T>* B = A + RB * NP;
+    cx<T>* twl = B + RB * NP;
     fft_load_twiddles<T>(twl, a.tw, N);
     const int e = blockIdx.z, th = blockIdx.y, y0 = blockIdx.x * RB;
     const int nrow = min(RB, R - y0);
@@ -51,30 +55,33 @@ __global__ void __launch_bounds__(256) k_pyr_rows(const PyrArgs<T> a) {
                 v = {am * c, am * s};
             }
         }
-        A[i] = v;
+        A[r * NP + xg] = v;
     }
     cx<T>* out = fft_lds<T>(A, B, a.plan, RB, twl, 0);
     cx<T>* t1 = a.t1 + (((size_t)e * a.n_theta_chunk + th) * R + y0) * N;
-    for (int i = threadIdx.x; i < nrow * N; i += blockDim.x) t1[i] = out[i];
+    for (int i = threadIdx.x; i < nrow * N; i += blockDim.x) {
+        const int r = i / N;
+        t1[i] = out[r * NP + (i - r * N)];
+    }
 }
 
 // P2: grid = (N / CB, chunk, E); CB columns per workgroup
 template <typename T>
 __global__ void __launch_bounds__(256) k_pyr_cols(const PyrArgs<T> a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    const int N = a.N, R = a.R, CB = a.seq_per_block;
+    const int N = a.N, NP = a.plan.np, R = a.R, CB = a.seq_per_block;
     cx<T>* A = reinterpret_cast<cx<T>*>(lds_raw);
-    cx<T>* B = A + CB * N;
-    cx<T>* twl = B + CB * N;
+    cx<T>* B = A + CB * NP;
+    cx<T>* twl = B + CB * NP;
     fft_load_twiddles<T>(twl, a.tw, N);
     const int e = blockIdx.z, th = blockIdx.y, kx0 = blockIdx.x * CB;
     const cx<T>* t1 = a.t1 + ((size_t)e * a.n_theta_chunk + th) * R * N;
     // gather: sequence c = column kx0 + c, element y (zero outside the pupil rows)
-    for (int i = threadIdx.x; i < CB * N; i += blockDim.x) A[i] = {0, 0};
+    for (int i = threadIdx.x; i < CB * NP; i += blockDim.x) A[i] = {0, 0};
     __syncthreads();
     for (int i = threadIdx.x; i < R * CB; i += blockDim.x) {
         const int y = i / CB, c = i - y * CB;                     // lanes along the columns: contiguous in T1
-        A[c * N + a.off + y] = t1[(size_t)y * N + kx0 + c];
+        A[c * NP + a.off + y] = t1[(size_t)y * N + kx0 + c];       // (odd sequence stride NP: the CB lanes hit CB banks)
     }
     cx<T>* f = fft_lds<T>(A, B, a.plan, CB, twl, 0);
     cx<T>* g = (f == A) ? B : A;
@@ -83,16 +90,16 @@ __global__ void __launch_bounds__(256) k_pyr_cols(const PyrArgs<T> a) {
     for (int i = threadIdx.x; i < CB * N; i += blockDim.x) {
         const int c = i / N, ky = i - c * N;                      // output (shifted) row index ky
         const int jx = (kx0 + c + h) % N;                         // output (shifted) column of frequency kx0 + c
-        const cx<T> v = f[c * N + (ky + h) % N];
+        const cx<T> v = f[c * NP + (ky + h) % N];
         const T* mk = a.mask + 2 * ((size_t)ky * N + jx);
-        g[i] = cmul(v, cx<T>{mk[0], mk[1]});
+        g[c * NP + ky] = cmul(v, cx<T>{mk[0], mk[1]});
     }
     cx<T>* r = fft_lds<T>(g, f, a.plan, CB, twl, 1);
     cx<T>* t2 = a.t2 + ((size_t)e * a.n_theta_chunk + th) * N * N;
     const int jx0 = (kx0 + h) % N;                                // CB divides N/2: the block's columns stay contiguous
     for (int i = threadIdx.x; i < N * CB; i += blockDim.x) {
         const int ky = i / CB, c = i - ky * CB;
-        t2[(size_t)ky * N + jx0 + c] = r[c * N + ky];
+        t2[(size_t)ky * N + jx0 + c] = r[c * NP + ky];
     }
 }
 
@@ -102,18 +109,18 @@ __global__ void __launch_bounds__(256) k_pyr_cols(const PyrArgs<T> a) {
 template <typename T>
 __global__ void __launch_bounds__(256) k_psf_cols(const PyrArgs<T> a, T* __restrict__ psf) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    const int N = a.N, R = a.R, CB = a.seq_per_block;
+    const int N = a.N, NP = a.plan.np, R = a.R, CB = a.seq_per_block;
     cx<T>* A = reinterpret_cast<cx<T>*>(lds_raw);
-    cx<T>* B = A + CB * N;
-    cx<T>* twl = B + CB * N;
+    cx<T>* B = A + CB * NP;
+    cx<T>* twl = B + CB * NP;
     fft_load_twiddles<T>(twl, a.tw, N);
     const int e = blockIdx.z, kx0 = blockIdx.x * CB;
     const cx<T>* t1 = a.t1 + (size_t)e * R * N;
-    for (int i = threadIdx.x; i < CB * N; i += blockDim.x) A[i] = {0, 0};
+    for (int i = threadIdx.x; i < CB * NP; i += blockDim.x) A[i] = {0, 0};
     __syncthreads();
     for (int i = threadIdx.x; i < R * CB; i += blockDim.x) {
         const int y = i / CB, c = i - y * CB;
-        A[c * N + a.off + y] = t1[(size_t)y * N + kx0 + c];
+        A[c * NP + a.off + y] = t1[(size_t)y * N + kx0 + c];
     }
     cx<T>* f = fft_lds<T>(A, B, a.plan, CB, twl, 0);
     // 2 x 2 sum-binning of |.|^2 (the reference's oversampling quirk, Telescope.py:303-305, 341-343): the PSF is M x M, M = N / 2
@@ -128,7 +135,7 @@ __global__ void __launch_bounds__(256) k_psf_cols(const PyrArgs<T> a, T* __restr
         for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
             for (int dx = 0; dx < 2; ++dx) {
-                const cx<T> v = f[(2 * c2 + dx) * N + (2 * k2 + dy + h) % N];   // shifted row ky holds frequency (ky + h) mod N
+                const cx<T> v = f[(2 * c2 + dx) * NP + (2 * k2 + dy + h) % N];   // shifted row ky holds frequency (ky + h) mod N
                 acc += (v.re * v.re + v.im * v.im) * scale;
             }
         out[(size_t)k2 * M + jx0 / 2 + c2] = acc;
@@ -139,13 +146,15 @@ template <typename T>
 int launch_psf(const PyrArgs<T>& base, T* psf, hipStream_t st) {
     PyrArgs<T> a = base;
     const int N = a.N, R = a.R;
-    int rb = (int)(64 * 1024 / (2 * (size_t)N * sizeof(cx<T>)));
+    const int NP = a.plan.np;
+    int rb = (int)(kFftLdsTarget / (2 * (size_t)NP * sizeof(cx<T>)));
+    if (rb < 2) rb = (int)std::min<size_t>(2, 160 * 1024 / ((2 * (size_t)NP + N) * sizeof(cx<T>)));   // the column pass bins pairs
     if (rb < 1) return fail("psf: N = %d does not fit two LDS row buffers", N);
     rb = rb > 8 ? 8 : rb;
     int cb = rb & ~1;
     while (cb > 2 && (N / 2) % cb) cb -= 2;
     if (cb < 2 || (N / 2) % cb || (N / 2) % 2) return fail("psf: N = %d has no even column block", N);
-    const size_t lds1 = (size_t)(2 * rb * N + N) * sizeof(cx<T>), lds2 = (size_t)(2 * cb * N + N) * sizeof(cx<T>);
+    const size_t lds1 = (size_t)(2 * rb * NP + N) * sizeof(cx<T>), lds2 = (size_t)(2 * cb * NP + N) * sizeof(cx<T>);
     if (lds1 > 64 * 1024)
         AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyr_rows<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
     if (lds2 > 64 * 1024)
@@ -166,10 +175,10 @@ template int launch_psf<double>(const PyrArgs<double>&, double*, hipStream_t);
 template <typename T>
 __global__ void __launch_bounds__(256) k_pyr_rows_inv(const PyrArgs<T> a, int accumulate) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    const int N = a.N, nb = N / a.cam;
+    const int N = a.N, NP = a.plan.np, nb = N / a.cam;
     cx<T>* A = reinterpret_cast<cx<T>*>(lds_raw);
-    cx<T>* B = A + nb * N;
-    cx<T>* twl = B + nb * N;
+    cx<T>* B = A + nb * NP;
+    cx<T>* twl = B + nb * NP;
     T* acc = reinterpret_cast<T*>(twl + N);                       // [N] column sums of |.|^2 over the nb rows and the chunk
     fft_load_twiddles<T>(twl, a.tw, N);
     const int e = blockIdx.y, cr = blockIdx.x;
@@ -178,12 +187,15 @@ __global__ void __launch_bounds__(256) k_pyr_rows_inv(const PyrArgs<T> a, int ac
     for (int th = 0; th < a.n_theta_chunk; ++th) {
         const cx<T>* t2 = a.t2 + (((size_t)e * a.n_theta_chunk + th) * N + (size_t)cr * nb) * N;
         __syncthreads();
-        for (int i = threadIdx.x; i < nb * N; i += blockDim.x) A[i] = t2[i];
+        for (int i = threadIdx.x; i < nb * N; i += blockDim.x) {
+            const int q = i / N;
+            A[q * NP + (i - q * N)] = t2[i];
+        }
         cx<T>* r = fft_lds<T>(A, B, a.plan, nb, twl, 1);
         for (int x = threadIdx.x; x < N; x += blockDim.x) {
             T s = 0;
             for (int q = 0; q < nb; ++q) {
-                const cx<T> v = r[q * N + x];
+                const cx<T> v = r[q * NP + x];
                 s += (v.re * v.re + v.im * v.im) * scale;
             }
             acc[x] += s;
@@ -238,14 +250,16 @@ int launch_pyramid(const PyrArgs<T>& base, int n_theta, int chunk, hipStream_t s
     PyrArgs<T> a = base;
     const int N = a.N, R = a.R;
     // sequences per workgroup: keep the two LDS buffers within 64 KiB (P3 may need more: raised explicitly)
-    int rb = (int)(64 * 1024 / (2 * (size_t)N * sizeof(cx<T>)));
+    const int NP = a.plan.np;
+    int rb = (int)(kFftLdsTarget / (2 * (size_t)NP * sizeof(cx<T>)));
+    rb = rb < 1 ? (int)(160 * 1024 / ((2 * (size_t)NP + N) * sizeof(cx<T>))) : rb;
     if (rb < 1) return fail("pyramid: nRes = %d does not fit two LDS row buffers", N);
     rb = rb > 8 ? 8 : rb;
     int cb = rb;
     while (cb > 1 && (N / 2) % cb) --cb;                          // CB must divide N/2 (fftshift keeps a block's columns contiguous)
     const int nb = N / a.cam;
-    const size_t lds3 = (size_t)(2 * nb * N + N) * sizeof(cx<T>) + (size_t)N * sizeof(T);
-    const size_t lds1 = (size_t)(2 * rb * N + N) * sizeof(cx<T>), lds2 = (size_t)(2 * cb * N + N) * sizeof(cx<T>);
+    const size_t lds3 = (size_t)(2 * nb * NP + N) * sizeof(cx<T>) + (size_t)N * sizeof(T);
+    const size_t lds1 = (size_t)(2 * rb * NP + N) * sizeof(cx<T>), lds2 = (size_t)(2 * cb * NP + N) * sizeof(cx<T>);
     if (lds1 > 64 * 1024)
         AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyr_rows<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
     if (lds2 > 64 * 1024)
@@ -282,6 +296,7 @@ template int launch_pyramid<double>(const PyrArgs<double>&, int, int, hipStream_
 // radix list for the Stockham transform: 4s first, then 2, 3, 5, then whatever prime factors remain
 int make_fft_plan(int n, FftPlan* pl) {
     pl->n = n;
+    pl->np = n | 1;
     pl->n_fac = 0;
     int m = n;
     auto push = [&](int r) { if (pl->n_fac < 12) pl->fac[pl->n_fac++] = r; };

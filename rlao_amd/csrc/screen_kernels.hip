@@ -18,8 +18,9 @@ __global__ void __launch_bounds__(256) k_screen_rows(const ScreenArgs a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int N = a.N, RB = a.seq_per_block, h = N / 2;
     cx<double>* A = reinterpret_cast<cx<double>*>(lds_raw);
-    cx<double>* B = A + RB * N;
-    cx<double>* twl = B + RB * N;
+    const int NP = a.plan.np;
+    cx<double>* B = A + RB * NP;
+    cx<double>* twl = B + RB * NP;
     fft_load_twiddles<double>(twl, a.tw, N);
     const int e = blockIdx.y, y0 = blockIdx.x * RB;
     const int nrow = min(RB, N - y0);
@@ -34,11 +35,14 @@ __global__ void __launch_bounds__(256) k_screen_rows(const ScreenArgs a) {
             const double w = a.amp[q];
             v = {re[q] * w, im[q] * w};
         }
-        A[i] = v;
+        A[r * NP + x] = v;
     }
     cx<double>* out = fft_lds<double>(A, B, a.plan, RB, twl, 0);
     cx<double>* dst = a.scratch + ((size_t)e * N + y0) * N;
-    for (int i = threadIdx.x; i < nrow * N; i += blockDim.x) dst[i] = out[i];
+    for (int i = threadIdx.x; i < nrow * N; i += blockDim.x) {
+        const int r = i / N;
+        dst[i] = out[r * NP + (i - r * N)];
+    }
 }
 
 // columns: FFT along y, output fftshift, real part
@@ -46,21 +50,22 @@ __global__ void __launch_bounds__(256) k_screen_cols(const ScreenArgs a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int N = a.N, CB = a.seq_per_block, h = N / 2;
     cx<double>* A = reinterpret_cast<cx<double>*>(lds_raw);
-    cx<double>* B = A + CB * N;
-    cx<double>* twl = B + CB * N;
+    const int NP = a.plan.np;
+    cx<double>* B = A + CB * NP;
+    cx<double>* twl = B + CB * NP;
     fft_load_twiddles<double>(twl, a.tw, N);
     const int e = blockIdx.y, x0 = blockIdx.x * CB;
     const int ncol = min(CB, N - x0);
     const cx<double>* src = a.scratch + (size_t)e * N * N;
     for (int i = threadIdx.x; i < N * CB; i += blockDim.x) {
         const int y = i / CB, c = i - y * CB;
-        A[c * N + y] = c < ncol ? src[(size_t)y * N + x0 + c] : cx<double>{0, 0};
+        A[c * NP + y] = c < ncol ? src[(size_t)y * N + x0 + c] : cx<double>{0, 0};
     }
     cx<double>* out = fft_lds<double>(A, B, a.plan, CB, twl, 0);
     double* hi = a.hi + (size_t)e * N * N;
     for (int i = threadIdx.x; i < N * CB; i += blockDim.x) {
         const int y = i / CB, c = i - y * CB;
-        if (c < ncol) hi[(size_t)((y + h) % N) * N + (x0 + c + h) % N] = out[c * N + y].re;
+        if (c < ncol) hi[(size_t)((y + h) % N) * N + (x0 + c + h) % N] = out[c * NP + y].re;
     }
 }
 
@@ -120,11 +125,12 @@ template <typename T>
 int launch_screen(const ScreenArgs& base, T* map, int S, hipStream_t st) {
     ScreenArgs a = base;
     const int N = a.N;
-    int rb = (int)(60 * 1024 / (2 * (size_t)N * sizeof(cx<double>)));
+    const int NP = a.plan.np;
+    int rb = (int)(60 * 1024 / (2 * (size_t)NP * sizeof(cx<double>)));
     if (rb < 1) return fail("screen generator: N = %d does not fit two LDS row buffers", N);
     rb = rb > 8 ? 8 : rb;
     a.seq_per_block = rb;
-    const size_t lds = (2 * (size_t)rb * N + N) * sizeof(cx<double>);
+    const size_t lds = (2 * (size_t)rb * NP + N) * sizeof(cx<double>);
     if (lds > 64 * 1024) {
         AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_screen_rows), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_screen_cols), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
