@@ -25,8 +25,52 @@ __device__ inline cx<T> tw_lds(const cx<T>* __restrict__ twl, int k, int inverse
     if (inverse) w.im = -w.im;
     return w;
 }
+// Position of element i of a sequence in LDS: one slot of padding after every 16.  A first stage of radix R writes its
+// outputs R apart (radix 16: 32 dwords = every lane in the same bank); with the padding lane j lands 17 slots after lane
+// j - 1.  Every buffer the transform touches -- the caller's input and the result included -- is indexed through fpad().
+__host__ __device__ inline int fpad(int i) { return i + (i >> 4); }
 // x / d for x < 2^16 with magic = floor(2^32 / d) + 1 (make_fft_plan)
 __device__ inline int fastdiv(int x, unsigned magic) { return (int)__umulhi((unsigned)x, magic); }
+
+// Length-4 DFT in place (forward: W_4 = -i; inverse: +i).
+template <typename T>
+__device__ inline void dft4(cx<T>& x0, cx<T>& x1, cx<T>& x2, cx<T>& x3, int inverse) {
+    const cx<T> a = cadd(x0, x2), b = csub(x0, x2), c = cadd(x1, x3), d = csub(x1, x3);
+    const cx<T> dj = inverse ? cx<T>{-d.im, d.re} : cx<T>{d.im, -d.re};
+    x0 = cadd(a, c);
+    x1 = cadd(b, dj);
+    x2 = csub(a, c);
+    x3 = csub(b, dj);
+}
+// Length-16 DFT in registers as 4 x 4: r = 4 r1 + r0, q = q0 + 4 q1,  W_16^{q r} = W_4^{q0 r1} W_16^{q0 r0} W_4^{q1 r0}.
+template <typename T>
+__device__ inline void dft16(cx<T> (&v)[16], cx<T> (&y)[16], int inverse) {
+    // cos / sin of 2 pi k / 16, k = 1, 2, 3
+    constexpr double c1 = 0.92387953251128673848, s1 = 0.38268343236508978178, c2 = 0.70710678118654752440;
+#pragma unroll
+    for (int r0 = 0; r0 < 4; ++r0) dft4<T>(v[r0], v[4 + r0], v[8 + r0], v[12 + r0], inverse);   // over r1: v[4 q0 + r0] = t[r0][q0]
+    // t[r0][q0] *= W_16^{q0 r0}: exponents 1 2 3 / 2 4 6 / 3 6 9
+    const T sg = inverse ? (T)1 : (T)-1;                         // forward: exp(-i x)
+    auto rot = [&](cx<T>& x, double c, double sn) { x = cmul(x, cx<T>{(T)c, sg * (T)sn}); };
+    rot(v[4 * 1 + 1], c1, s1);            // k = 1
+    rot(v[4 * 1 + 2], c2, c2);            // k = 2
+    rot(v[4 * 1 + 3], s1, c1);            // k = 3
+    rot(v[4 * 2 + 1], c2, c2);            // k = 2
+    rot(v[4 * 2 + 2], 0.0, 1.0);          // k = 4
+    rot(v[4 * 2 + 3], -c2, c2);           // k = 6
+    rot(v[4 * 3 + 1], s1, c1);            // k = 3
+    rot(v[4 * 3 + 2], -c2, c2);           // k = 6
+    rot(v[4 * 3 + 3], -c1, -s1);          // k = 9
+#pragma unroll
+    for (int q0 = 0; q0 < 4; ++q0) {
+        cx<T> a0 = v[4 * q0], a1 = v[4 * q0 + 1], a2 = v[4 * q0 + 2], a3 = v[4 * q0 + 3];       // over r0
+        dft4<T>(a0, a1, a2, a3, inverse);
+        y[q0] = a0;
+        y[q0 + 4] = a1;
+        y[q0 + 8] = a2;
+        y[q0 + 12] = a3;
+    }
+}
 
 // One Stockham stage over `nseq` sequences stored [seq][n] in LDS (src -> dst), all lanes of the workgroup cooperate.
 // Butterfly j of a sequence reads src[j + r m] (m = n / R), multiplies by w_{ns R}^{k r} = w_n^{k r tstep} with k = j mod ns,
@@ -44,12 +88,14 @@ __device__ inline void fft_stage_r(const cx<T>* __restrict__ src, cx<T>* __restr
         int ti = 0;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            v[r] = s[j + r * m];
-            if (r > 0) v[r] = cmul(v[r], tw_lds(twl, ti, inverse));
+            v[r] = s[fpad(j + r * m)];
+            if (r > 0 && ns > 1) v[r] = cmul(v[r], tw_lds(twl, ti, inverse));      // first stage: k = 0, every twiddle is 1
             ti += k * tstep;
         }
         cx<T> y[R];
-        if (R == 2) {
+        if constexpr (R == 16) {
+            dft16<T>(v, y, inverse);
+        } else if (R == 2) {
             y[0] = cadd(v[0], v[1]);
             y[1] = csub(v[0], v[1]);
         } else if (R == 4) {
@@ -69,9 +115,10 @@ __device__ inline void fft_stage_r(const cx<T>* __restrict__ src, cx<T>* __restr
                 y[q] = acc;
             }
         }
-        cx<T>* d = dst + seq * np + jd * ns * R + k;
+        cx<T>* d = dst + seq * np;
+        const int o = jd * ns * R + k;
 #pragma unroll
-        for (int q = 0; q < R; ++q) d[q * ns] = y[q];
+        for (int q = 0; q < R; ++q) d[fpad(o + q * ns)] = y[q];
     }
 }
 
@@ -100,7 +147,7 @@ __device__ inline void fft_stage_prime(const cx<T>* __restrict__ src, cx<T>* __r
         int ti = 0;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            v[r] = s[j + r * m];
+            v[r] = s[fpad(j + r * m)];
             if (r > 0) v[r] = cmul(v[r], tw_lds(twl, ti, inverse));
             ti += k * tstep;
         }
@@ -112,8 +159,9 @@ __device__ inline void fft_stage_prime(const cx<T>* __restrict__ src, cx<T>* __r
             b[r] = csub(v[r], v[R - r]);
             y0 = cadd(y0, a[r]);
         }
-        cx<T>* d = dst + seq * np + jd * ns * R + k;
-        d[0] = y0;
+        cx<T>* d = dst + seq * np;
+        const int o = jd * ns * R + k;
+        d[fpad(o)] = y0;
 #pragma unroll
         for (int q = 1; q <= H; ++q) {
             T cr = v[0].re, ci = v[0].im, sr = 0, si = 0;
@@ -127,8 +175,8 @@ __device__ inline void fft_stage_prime(const cx<T>* __restrict__ src, cx<T>* __r
                 si += b[r].im * S[p2];
             }
             // i b S = (-b.im S, b.re S)
-            d[q * ns] = {cr - si, ci + sr};
-            d[(R - q) * ns] = {cr + si, ci - sr};
+            d[fpad(o + q * ns)] = {cr - si, ci + sr};
+            d[fpad(o + (R - q) * ns)] = {cr + si, ci - sr};
         }
     }
 }
@@ -144,7 +192,7 @@ __device__ inline void fft_stage_any(cx<T>* __restrict__ src, cx<T>* __restrict_
         const int sr = fastdiv(w, magic_m), seq = sr / R, r = sr - seq * R, j = w - sr * m;   // (w / m) = seq R + r
         if (r > 0) {
             const int jd = ns == 1 ? j : fastdiv(j, magic_ns), k = j - jd * ns;
-            cx<T>* x = src + seq * np + r * m + j;
+            cx<T>* x = src + seq * np + fpad(r * m + j);
             *x = cmul(*x, tw_lds(twl, k * r * tstep, inverse));
         }
     }
@@ -153,15 +201,15 @@ __device__ inline void fft_stage_any(cx<T>* __restrict__ src, cx<T>* __restrict_
         const int sq = fastdiv(w, magic_m), j = w - sq * m;
         const int seq = sq / R, q = sq - seq * R;
         const int jd = ns == 1 ? j : fastdiv(j, magic_ns), k = j - jd * ns;
-        const cx<T>* s = src + seq * np + j;
-        cx<T> acc = s[0];
+        const cx<T>* s = src + seq * np;
+        cx<T> acc = s[fpad(j)];
         int qr = 0;
         for (int r = 1; r < R; ++r) {
             qr += q;
             qr = qr >= R ? qr - R : qr;
-            acc = cadd(acc, cmul(s[r * m], tw_lds(twl, qr * m, inverse)));
+            acc = cadd(acc, cmul(s[fpad(j + r * m)], tw_lds(twl, qr * m, inverse)));
         }
-        dst[seq * np + jd * ns * R + k + q * ns] = acc;
+        dst[seq * np + fpad(jd * ns * R + k + q * ns)] = acc;
     }
 }
 
@@ -182,6 +230,7 @@ __device__ inline cx<T>* fft_lds(cx<T>* a, cx<T>* b, const FftPlan& pl, int nseq
             case 5: fft_stage_r<T, 5>(src, dst, pl.n, pl.np, ns, pl.magic_ns[s], pl.magic_m[s], nseq, twl, inverse); break;
             case 7: fft_stage_prime<T, 7>(src, dst, pl.n, pl.np, ns, pl.magic_ns[s], pl.magic_m[s], nseq, twl, inverse); break;
             case 11: fft_stage_prime<T, 11>(src, dst, pl.n, pl.np, ns, pl.magic_ns[s], pl.magic_m[s], nseq, twl, inverse); break;
+            case 16: fft_stage_r<T, 16>(src, dst, pl.n, pl.np, ns, pl.magic_ns[s], pl.magic_m[s], nseq, twl, inverse); break;
             case 13: fft_stage_prime<T, 13>(src, dst, pl.n, pl.np, ns, pl.magic_ns[s], pl.magic_m[s], nseq, twl, inverse); break;
             default: fft_stage_any<T>(src, dst, pl.n, pl.np, ns, pl.magic_ns[s], pl.magic_m[s], nseq, R, twl, inverse); break;
         }

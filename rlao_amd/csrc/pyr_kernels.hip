@@ -55,13 +55,13 @@ __global__ void __launch_bounds__(256) k_pyr_rows(const PyrArgs<T> a) {
                 v = {am * c, am * s};
             }
         }
-        A[r * NP + xg] = v;
+        A[r * NP + fpad(xg)] = v;
     }
     cx<T>* out = fft_lds<T>(A, B, a.plan, RB, twl, 0);
     cx<T>* t1 = a.t1 + (((size_t)e * a.n_theta_chunk + th) * R + y0) * N;
     for (int i = threadIdx.x; i < nrow * N; i += blockDim.x) {
         const int r = i / N;
-        t1[i] = out[r * NP + (i - r * N)];
+        t1[i] = out[r * NP + fpad(i - r * N)];
     }
 }
 
@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(256) k_pyr_cols(const PyrArgs<T> a) {
     __syncthreads();
     for (int i = threadIdx.x; i < R * CB; i += blockDim.x) {
         const int y = i / CB, c = i - y * CB;                     // lanes along the columns: contiguous in T1
-        A[c * NP + a.off + y] = t1[(size_t)y * N + kx0 + c];       // (odd sequence stride NP: the CB lanes hit CB banks)
+        A[c * NP + fpad(a.off + y)] = t1[(size_t)y * N + kx0 + c];       // (odd sequence stride NP: the CB lanes hit CB banks)
     }
     cx<T>* f = fft_lds<T>(A, B, a.plan, CB, twl, 0);
     cx<T>* g = (f == A) ? B : A;
@@ -90,16 +90,16 @@ __global__ void __launch_bounds__(256) k_pyr_cols(const PyrArgs<T> a) {
     for (int i = threadIdx.x; i < CB * N; i += blockDim.x) {
         const int c = i / N, ky = i - c * N;                      // output (shifted) row index ky
         const int jx = (kx0 + c + h) % N;                         // output (shifted) column of frequency kx0 + c
-        const cx<T> v = f[c * NP + (ky + h) % N];
+        const cx<T> v = f[c * NP + fpad((ky + h) % N)];
         const T* mk = a.mask + 2 * ((size_t)ky * N + jx);
-        g[c * NP + ky] = cmul(v, cx<T>{mk[0], mk[1]});
+        g[c * NP + fpad(ky)] = cmul(v, cx<T>{mk[0], mk[1]});
     }
     cx<T>* r = fft_lds<T>(g, f, a.plan, CB, twl, 1);
     cx<T>* t2 = a.t2 + ((size_t)e * a.n_theta_chunk + th) * N * N;
     const int jx0 = (kx0 + h) % N;                                // CB divides N/2: the block's columns stay contiguous
     for (int i = threadIdx.x; i < N * CB; i += blockDim.x) {
         const int ky = i / CB, c = i - ky * CB;
-        t2[(size_t)ky * N + jx0 + c] = r[c * NP + ky];
+        t2[(size_t)ky * N + jx0 + c] = r[c * NP + fpad(ky)];
     }
 }
 
@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(256) k_psf_cols(const PyrArgs<T> a, T* __restr
     __syncthreads();
     for (int i = threadIdx.x; i < R * CB; i += blockDim.x) {
         const int y = i / CB, c = i - y * CB;
-        A[c * NP + a.off + y] = t1[(size_t)y * N + kx0 + c];
+        A[c * NP + fpad(a.off + y)] = t1[(size_t)y * N + kx0 + c];
     }
     cx<T>* f = fft_lds<T>(A, B, a.plan, CB, twl, 0);
     // 2 x 2 sum-binning of |.|^2 (the reference's oversampling quirk, Telescope.py:303-305, 341-343): the PSF is M x M, M = N / 2
@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(256) k_psf_cols(const PyrArgs<T> a, T* __restr
         for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
             for (int dx = 0; dx < 2; ++dx) {
-                const cx<T> v = f[(2 * c2 + dx) * NP + (2 * k2 + dy + h) % N];   // shifted row ky holds frequency (ky + h) mod N
+                const cx<T> v = f[(2 * c2 + dx) * NP + fpad((2 * k2 + dy + h) % N)];   // shifted row ky holds frequency (ky + h) mod N
                 acc += (v.re * v.re + v.im * v.im) * scale;
             }
         out[(size_t)k2 * M + jx0 / 2 + c2] = acc;
@@ -189,13 +189,13 @@ __global__ void __launch_bounds__(256) k_pyr_rows_inv(const PyrArgs<T> a, int ac
         __syncthreads();
         for (int i = threadIdx.x; i < nb * N; i += blockDim.x) {
             const int q = i / N;
-            A[q * NP + (i - q * N)] = t2[i];
+            A[q * NP + fpad(i - q * N)] = t2[i];
         }
         cx<T>* r = fft_lds<T>(A, B, a.plan, nb, twl, 1);
         for (int x = threadIdx.x; x < N; x += blockDim.x) {
             T s = 0;
             for (int q = 0; q < nb; ++q) {
-                const cx<T> v = r[q * NP + x];
+                const cx<T> v = r[q * NP + fpad(x)];
                 s += (v.re * v.re + v.im * v.im) * scale;
             }
             acc[x] += s;
@@ -293,13 +293,14 @@ template int launch_pyramid_slopes<double>(const PyrSlopeArgs<double>&, int, hip
 template int launch_pyramid<float>(const PyrArgs<float>&, int, int, hipStream_t);
 template int launch_pyramid<double>(const PyrArgs<double>&, int, int, hipStream_t);
 
-// radix list for the Stockham transform: 4s first, then 2, 3, 5, then whatever prime factors remain
+// radix list for the Stockham transform: 16s and 4s first, then 2, 3, 5, then whatever prime factors remain
 int make_fft_plan(int n, FftPlan* pl) {
     pl->n = n;
-    pl->np = n | 1;
+    pl->np = (fpad(n - 1) + 1) | 1;
     pl->n_fac = 0;
     int m = n;
     auto push = [&](int r) { if (pl->n_fac < 12) pl->fac[pl->n_fac++] = r; };
+    while (m % 16 == 0) { push(16); m /= 16; }                    // register-resident 4 x 4 butterflies: half the stages (barriers)
     while (m % 4 == 0) { push(4); m /= 4; }
     while (m % 2 == 0) { push(2); m /= 2; }
     while (m % 3 == 0) { push(3); m /= 3; }

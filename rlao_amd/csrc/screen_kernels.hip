@@ -35,13 +35,13 @@ __global__ void __launch_bounds__(256) k_screen_rows(const ScreenArgs a) {
             const double w = a.amp[q];
             v = {re[q] * w, im[q] * w};
         }
-        A[r * NP + x] = v;
+        A[r * NP + fpad(x)] = v;
     }
     cx<double>* out = fft_lds<double>(A, B, a.plan, RB, twl, 0);
     cx<double>* dst = a.scratch + ((size_t)e * N + y0) * N;
     for (int i = threadIdx.x; i < nrow * N; i += blockDim.x) {
         const int r = i / N;
-        dst[i] = out[r * NP + (i - r * N)];
+        dst[i] = out[r * NP + fpad(i - r * N)];
     }
 }
 
@@ -59,13 +59,13 @@ __global__ void __launch_bounds__(256) k_screen_cols(const ScreenArgs a) {
     const cx<double>* src = a.scratch + (size_t)e * N * N;
     for (int i = threadIdx.x; i < N * CB; i += blockDim.x) {
         const int y = i / CB, c = i - y * CB;
-        A[c * NP + y] = c < ncol ? src[(size_t)y * N + x0 + c] : cx<double>{0, 0};
+        A[c * NP + fpad(y)] = c < ncol ? src[(size_t)y * N + x0 + c] : cx<double>{0, 0};
     }
     cx<double>* out = fft_lds<double>(A, B, a.plan, CB, twl, 0);
     double* hi = a.hi + (size_t)e * N * N;
     for (int i = threadIdx.x; i < N * CB; i += blockDim.x) {
         const int y = i / CB, c = i - y * CB;
-        if (c < ncol) hi[(size_t)((y + h) % N) * N + (x0 + c + h) % N] = out[c * NP + y].re;
+        if (c < ncol) hi[(size_t)((y + h) % N) * N + (x0 + c + h) % N] = out[c * NP + fpad(y)].re;
     }
 }
 
