@@ -239,6 +239,7 @@ struct PyrArgs {
     T* frame;              // [E][cam*cam]
     FftPlan plan;
     int R, N, cam, off, centering, theta0, n_theta_chunk, n_env, seq_per_block;
+    unsigned magic_seq;    // floor(2^32 / seq_per_block) + 1: i / seq_per_block for i < 2^16 without a division (set by the launchers)
     int phasor_mult;       // the pupil field is multiplied by exp(-i pi m (x + y) / N) on the padded grid: m = N + 1 (Pyramid with a
                            // centred mask, Pyramid.py:294), 1 (science PSF, Telescope.py:316), 0 (none)
 };

@@ -225,9 +225,9 @@ __device__ inline cx<T>* fft_lds(cx<T>* a, cx<T>* b, const FftPlan& pl, int nseq
         __syncthreads();
         switch (R) {
             case 2: fft_stage_r<T, 2>(src, dst, pl.n, pl.np, ns, pl.magic_ns[s], pl.magic_m[s], nseq, twl, inverse); break;
-            case 3: fft_stage_r<T, 3>(src, dst, pl.n, pl.np, ns, pl.magic_ns[s], pl.magic_m[s], nseq, twl, inverse); break;
+            case 3: fft_stage_prime<T, 3>(src, dst, pl.n, pl.np, ns, pl.magic_ns[s], pl.magic_m[s], nseq, twl, inverse); break;
             case 4: fft_stage_r<T, 4>(src, dst, pl.n, pl.np, ns, pl.magic_ns[s], pl.magic_m[s], nseq, twl, inverse); break;
-            case 5: fft_stage_r<T, 5>(src, dst, pl.n, pl.np, ns, pl.magic_ns[s], pl.magic_m[s], nseq, twl, inverse); break;
+            case 5: fft_stage_prime<T, 5>(src, dst, pl.n, pl.np, ns, pl.magic_ns[s], pl.magic_m[s], nseq, twl, inverse); break;
             case 7: fft_stage_prime<T, 7>(src, dst, pl.n, pl.np, ns, pl.magic_ns[s], pl.magic_m[s], nseq, twl, inverse); break;
             case 11: fft_stage_prime<T, 11>(src, dst, pl.n, pl.np, ns, pl.magic_ns[s], pl.magic_m[s], nseq, twl, inverse); break;
             case 16: fft_stage_r<T, 16>(src, dst, pl.n, pl.np, ns, pl.magic_ns[s], pl.magic_m[s], nseq, twl, inverse); break;

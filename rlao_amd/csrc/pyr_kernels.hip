@@ -37,8 +37,10 @@ __global__ void __launch_bounds__(256) k_pyr_rows(const PyrArgs<T> a) {
     const T* ph = a.phase + (size_t)e * R * R;
     const T* tt = a.tt ? a.tt + (size_t)(a.theta0 + th) * R * R : nullptr;
     const T pi_over_n = (T)(3.14159265358979323846 / N);
-    for (int i = threadIdx.x; i < RB * N; i += blockDim.x) {
-        const int r = i / N, xg = i - r * N;
+    // (loops are (sequence, element) nests: an integer division by a run-time N per element costs as much as the butterflies)
+    const int two_n = 2 * N;
+    for (int r = 0; r < RB; ++r)
+    for (int xg = threadIdx.x; xg < N; xg += blockDim.x) {
         cx<T> v = {0, 0};
         const int x = xg - a.off;
         if (r < nrow && x >= 0 && x < R) {
@@ -49,7 +51,7 @@ __global__ void __launch_bounds__(256) k_pyr_rows(const PyrArgs<T> a) {
                 if (tt) ang += tt[p];
                 // centred mask: the field is multiplied by exp(-i pi (N+1)/N (x + y)) on the padded grid (Pyramid.py:294, 486)
                 // the angle pi (N+1) k / N is reduced mod 2 pi in integers (k up to 2N would cost float32 1e-4 rad)
-                if (a.phasor_mult) ang -= pi_over_n * (T)((a.phasor_mult * (xg + y0 + r + a.off)) % (2 * N));
+                if (a.phasor_mult) ang -= pi_over_n * (T)((a.phasor_mult * (xg + y0 + r + a.off)) % two_n);
                 T s, c;
                 sincos_g<T>(ang, &s, &c);
                 v = {am * c, am * s};
@@ -59,10 +61,8 @@ __global__ void __launch_bounds__(256) k_pyr_rows(const PyrArgs<T> a) {
     }
     cx<T>* out = fft_lds<T>(A, B, a.plan, RB, twl, 0);
     cx<T>* t1 = a.t1 + (((size_t)e * a.n_theta_chunk + th) * R + y0) * N;
-    for (int i = threadIdx.x; i < nrow * N; i += blockDim.x) {
-        const int r = i / N;
-        t1[i] = out[r * NP + fpad(i - r * N)];
-    }
+    for (int r = 0; r < nrow; ++r)
+        for (int x = threadIdx.x; x < N; x += blockDim.x) t1[(size_t)r * N + x] = out[r * NP + fpad(x)];
 }
 
 // P2: grid = (N / CB, chunk, E); CB columns per workgroup
@@ -74,31 +74,40 @@ __global__ void __launch_bounds__(256) k_pyr_cols(const PyrArgs<T> a) {
     cx<T>* B = A + CB * NP;
     cx<T>* twl = B + CB * NP;
     fft_load_twiddles<T>(twl, a.tw, N);
-    const int e = blockIdx.z, th = blockIdx.y, kx0 = blockIdx.x * CB;
+    // Column block of this workgroup.  gridDim.x is a multiple of 8 and workgroups go round-robin over the 8 XCDs, so
+    // blockIdx.x % 8 is the XCD: each XCD takes a contiguous range of column blocks.  A 128-byte line of T1 / T2 holds the
+    // columns of 16 / CB neighbouring blocks: on one XCD they share its L2 (one HBM read of the line, partial writes merged).
+    const int nblk = N / CB, per_xcd = gridDim.x / 8;
+    const int blk = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (blk >= nblk) return;                                      // padding of the grid (uniform for the workgroup)
+    const int e = blockIdx.z, th = blockIdx.y, kx0 = blk * CB;
     const cx<T>* t1 = a.t1 + ((size_t)e * a.n_theta_chunk + th) * R * N;
     // gather: sequence c = column kx0 + c, element y (zero outside the pupil rows)
     for (int i = threadIdx.x; i < CB * NP; i += blockDim.x) A[i] = {0, 0};
     __syncthreads();
     for (int i = threadIdx.x; i < R * CB; i += blockDim.x) {
-        const int y = i / CB, c = i - y * CB;                     // lanes along the columns: contiguous in T1
+        const int y = CB == 1 ? i : fastdiv(i, a.magic_seq), c = i - y * CB;     // lanes along the columns: contiguous in T1
         A[c * NP + fpad(a.off + y)] = t1[(size_t)y * N + kx0 + c];       // (odd sequence stride NP: the CB lanes hit CB banks)
     }
     cx<T>* f = fft_lds<T>(A, B, a.plan, CB, twl, 0);
     cx<T>* g = (f == A) ? B : A;
     // focal plane: [fftshift] + mask   (Pyramid.py:486-497).  Shifted position i holds frequency (i + N/2) mod N.
     const int h = a.centering ? 0 : N / 2;
-    for (int i = threadIdx.x; i < CB * N; i += blockDim.x) {
-        const int c = i / N, ky = i - c * N;                      // output (shifted) row index ky
-        const int jx = (kx0 + c + h) % N;                         // output (shifted) column of frequency kx0 + c
-        const cx<T> v = f[c * NP + fpad((ky + h) % N)];
-        const T* mk = a.mask + 2 * ((size_t)ky * N + jx);
-        g[c * NP + fpad(ky)] = cmul(v, cx<T>{mk[0], mk[1]});
+    for (int c = 0; c < CB; ++c) {
+        int jx = kx0 + c + h;                                     // output (shifted) column of frequency kx0 + c
+        jx = jx >= N ? jx - N : jx;
+        for (int ky = threadIdx.x; ky < N; ky += blockDim.x) {    // output (shifted) row index ky
+            const int src_y = ky + h >= N ? ky + h - N : ky + h;
+            const cx<T> v = f[c * NP + fpad(src_y)];
+            const T* mk = a.mask + 2 * ((size_t)ky * N + jx);
+            g[c * NP + fpad(ky)] = cmul(v, cx<T>{mk[0], mk[1]});
+        }
     }
     cx<T>* r = fft_lds<T>(g, f, a.plan, CB, twl, 1);
     cx<T>* t2 = a.t2 + ((size_t)e * a.n_theta_chunk + th) * N * N;
     const int jx0 = (kx0 + h) % N;                                // CB divides N/2: the block's columns stay contiguous
     for (int i = threadIdx.x; i < N * CB; i += blockDim.x) {
-        const int ky = i / CB, c = i - ky * CB;
+        const int ky = CB == 1 ? i : fastdiv(i, a.magic_seq), c = i - ky * CB;
         t2[(size_t)ky * N + jx0 + c] = r[c * NP + fpad(ky)];
     }
 }
@@ -119,7 +128,7 @@ __global__ void __launch_bounds__(256) k_psf_cols(const PyrArgs<T> a, T* __restr
     for (int i = threadIdx.x; i < CB * NP; i += blockDim.x) A[i] = {0, 0};
     __syncthreads();
     for (int i = threadIdx.x; i < R * CB; i += blockDim.x) {
-        const int y = i / CB, c = i - y * CB;
+        const int y = CB == 1 ? i : fastdiv(i, a.magic_seq), c = i - y * CB;
         A[c * NP + fpad(a.off + y)] = t1[(size_t)y * N + kx0 + c];
     }
     cx<T>* f = fft_lds<T>(A, B, a.plan, CB, twl, 0);
@@ -164,6 +173,7 @@ int launch_psf(const PyrArgs<T>& base, T* psf, hipStream_t st) {
     a.seq_per_block = rb;
     hipLaunchKernelGGL(k_pyr_rows<T>, dim3(cdiv(R, rb), 1, a.n_env), dim3(256), lds1, st, a);
     a.seq_per_block = cb;
+    a.magic_seq = (unsigned)((1ull << 32) / (unsigned)cb) + 1u;
     hipLaunchKernelGGL(k_psf_cols<T>, dim3(N / cb, 1, a.n_env), dim3(256), lds2, st, a, psf);
     AO_HIP(hipGetLastError());
     return 0;
@@ -175,10 +185,13 @@ template int launch_psf<double>(const PyrArgs<double>&, double*, hipStream_t);
 template <typename T>
 __global__ void __launch_bounds__(256) k_pyr_rows_inv(const PyrArgs<T> a, int accumulate) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    const int N = a.N, NP = a.plan.np, nb = N / a.cam;
+    // the nb rows of a camera row go through LDS in sub-batches of SB = seq_per_block rows (two buffers of SB sequences:
+    // ~28 KB instead of 2 nb rows = 54 KB at nRes 528, i.e. 5 resident workgroups per CU instead of 2 -- the kernel waits on
+    // barriers and on the HBM read of its rows, not on arithmetic)
+    const int N = a.N, NP = a.plan.np, nb = N / a.cam, SB = a.seq_per_block;
     cx<T>* A = reinterpret_cast<cx<T>*>(lds_raw);
-    cx<T>* B = A + nb * NP;
-    cx<T>* twl = B + nb * NP;
+    cx<T>* B = A + SB * NP;
+    cx<T>* twl = B + SB * NP;
     T* acc = reinterpret_cast<T*>(twl + N);                       // [N] column sums of |.|^2 over the nb rows and the chunk
     fft_load_twiddles<T>(twl, a.tw, N);
     const int e = blockIdx.y, cr = blockIdx.x;
@@ -186,19 +199,21 @@ __global__ void __launch_bounds__(256) k_pyr_rows_inv(const PyrArgs<T> a, int ac
     const T scale = (T)1 / ((T)N * (T)N * (T)N * (T)N);            // ifft2 normalisation 1/N^2 on the amplitude
     for (int th = 0; th < a.n_theta_chunk; ++th) {
         const cx<T>* t2 = a.t2 + (((size_t)e * a.n_theta_chunk + th) * N + (size_t)cr * nb) * N;
-        __syncthreads();
-        for (int i = threadIdx.x; i < nb * N; i += blockDim.x) {
-            const int q = i / N;
-            A[q * NP + fpad(i - q * N)] = t2[i];
-        }
-        cx<T>* r = fft_lds<T>(A, B, a.plan, nb, twl, 1);
-        for (int x = threadIdx.x; x < N; x += blockDim.x) {
-            T s = 0;
-            for (int q = 0; q < nb; ++q) {
-                const cx<T> v = r[q * NP + fpad(x)];
-                s += (v.re * v.re + v.im * v.im) * scale;
+        for (int q0 = 0; q0 < nb; q0 += SB) {
+            const int ns = min(SB, nb - q0);
+            __syncthreads();
+            for (int q = 0; q < SB; ++q)
+                for (int x = threadIdx.x; x < N; x += blockDim.x)
+                    A[q * NP + fpad(x)] = q < ns ? t2[(size_t)(q0 + q) * N + x] : cx<T>{0, 0};
+            cx<T>* r = fft_lds<T>(A, B, a.plan, SB, twl, 1);
+            for (int x = threadIdx.x; x < N; x += blockDim.x) {
+                T s = 0;
+                for (int q = 0; q < ns; ++q) {
+                    const cx<T> v = r[q * NP + fpad(x)];
+                    s += (v.re * v.re + v.im * v.im) * scale;
+                }
+                acc[x] += s;
             }
-            acc[x] += s;
         }
     }
     __syncthreads();
@@ -258,7 +273,10 @@ int launch_pyramid(const PyrArgs<T>& base, int n_theta, int chunk, hipStream_t s
     int cb = rb;
     while (cb > 1 && (N / 2) % cb) --cb;                          // CB must divide N/2 (fftshift keeps a block's columns contiguous)
     const int nb = N / a.cam;
-    const size_t lds3 = (size_t)(2 * nb * NP + N) * sizeof(cx<T>) + (size_t)N * sizeof(T);
+    int sb = (int)(28 * 1024 / (2 * (size_t)NP * sizeof(cx<T>)));   // P3 waits on its HBM rows: 5 workgroups per CU
+    sb = sb < 1 ? 1 : (sb > nb ? nb : sb);
+    while (sb > 1 && nb % sb) --sb;                               // equal sub-batches of the nb rows of a camera row
+    const size_t lds3 = (size_t)(2 * sb * NP + N) * sizeof(cx<T>) + (size_t)N * sizeof(T);
     const size_t lds1 = (size_t)(2 * rb * NP + N) * sizeof(cx<T>), lds2 = (size_t)(2 * cb * NP + N) * sizeof(cx<T>);
     if (lds1 > 64 * 1024)
         AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyr_rows<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
@@ -274,7 +292,9 @@ int launch_pyramid(const PyrArgs<T>& base, int n_theta, int chunk, hipStream_t s
         a.seq_per_block = rb;
         hipLaunchKernelGGL(k_pyr_rows<T>, dim3(cdiv(R, rb), a.n_theta_chunk, a.n_env), dim3(256), lds1, st, a);
         a.seq_per_block = cb;
-        hipLaunchKernelGGL(k_pyr_cols<T>, dim3(N / cb, a.n_theta_chunk, a.n_env), dim3(256), lds2, st, a);
+        a.magic_seq = (unsigned)((1ull << 32) / (unsigned)cb) + 1u;
+        hipLaunchKernelGGL(k_pyr_cols<T>, dim3(cdiv(N / cb, 8) * 8, a.n_theta_chunk, a.n_env), dim3(256), lds2, st, a);
+        a.seq_per_block = sb;
         hipLaunchKernelGGL(k_pyr_rows_inv<T>, dim3(a.cam, a.n_env), dim3(256), lds3, st, a, t0 > 0 ? 1 : 0);
         AO_HIP(hipGetLastError());
     }
