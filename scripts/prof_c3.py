@@ -11,5 +11,5 @@ env.set_params(dict(cfg["geo"], nLoop=200), wfs_type=cfg["wfs"])
 print("init", time.perf_counter() - t0, flush=True)
 env.generate_new_phase_screen(17); env.dm.coefs = 0; env.measure(); env.reset_soft()
 env.run_integrator(0, 10); torch.cuda.synchronize()
-env._shard.profile(True); env.run_integrator(10, 5); prof = env._shard.profile_read(env._stream()); env._shard.profile(False)
+env._shard.profile(True); env.run_integrator(10, 30); prof = env._shard.profile_read(env._stream()); env._shard.profile(False)
 print({k: (round(1e3 * ms / c, 1), c) for k, (ms, c) in prof.items() if c})
