@@ -54,6 +54,31 @@ def test_switches_agree_small():
             np.testing.assert_allclose(r.cpu().numpy(), r0.cpu().numpy(), rtol=1e-4, atol=2e-5)
 
 
+def test_large_dm_row_products_agree():
+    """A DM of 37 x 37 actuators (more than 32 across: the KS = 32 register blocking of the matrix-core kernels, R = 216 > 128:
+    the separate phase / spots kernels).  Gy.C once per env in MFMA operand layout (k_dm_rows, AOENV_OPT_COEFS_IMAGE, the
+    default above 1024 actuators) vs every tile forming its own rows vs the float64 shard, in a closed loop."""
+    from rlao_amd import _lib as L
+    from rlao_amd.env import BatchedAOEnv
+    geo = dict(C2, nSubaperture=36, nPixelPerSubap=6, nModes=60)
+    outs = {}
+    for name, dtype, opt in (("rows", "f32", 1), ("tiles", "f32", 0), ("f64", "f64", 0)):
+        env = BatchedAOEnv(n_envs=2, device=0, dtype=dtype)
+        env.set_params(geo, wfs_type="shackhartmann")
+        assert env.nActuator == 37 and env.R == 216
+        L.check(env._shard.lib.aoenv_set_option(env._shard.h, L.OPT_COEFS_IMAGE, opt))
+        outs[name] = _run(env, 6, 11)
+        env.close()
+    for (o, f, r, s), (o1, f1, r1, s1), (o2, f2, r2, s2) in zip(outs["rows"], outs["tiles"], outs["f64"]):
+        scale = float(o2.abs().max())
+        np.testing.assert_allclose(o.cpu().numpy(), o1.cpu().numpy(), atol=2e-5 * scale)
+        np.testing.assert_allclose(o.cpu().numpy(), o2.cpu().numpy(), atol=1e-2 * scale)     # float32 slopes through the reconstructor
+        np.testing.assert_allclose(f.cpu().numpy(), f1.cpu().numpy(), atol=2e-5 * float(f1.max()))
+        np.testing.assert_allclose(f.cpu().numpy(), f2.cpu().numpy(), atol=2e-3 * float(f2.max()))
+        np.testing.assert_allclose(s.cpu().numpy(), s1.cpu().numpy(), atol=1e-5)
+        np.testing.assert_allclose(s.cpu().numpy(), s2.cpu().numpy(), atol=1e-3)
+
+
 def test_full_size_batch_invariance_and_determinism():
     """256 envs of the BASELINE geometry: identical seeds give bitwise identical envs wherever they sit in the
     batch, a second run reproduces every bit (no atomics-order dependence), different seeds differ."""
