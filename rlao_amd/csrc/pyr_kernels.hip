@@ -85,9 +85,20 @@ __global__ void __launch_bounds__(256) k_pyr_cols(const PyrArgs<T> a) {
     // gather: sequence c = column kx0 + c, element y (zero outside the pupil rows)
     for (int i = threadIdx.x; i < CB * NP; i += blockDim.x) A[i] = {0, 0};
     __syncthreads();
-    for (int i = threadIdx.x; i < R * CB; i += blockDim.x) {
-        const int y = CB == 1 ? i : fastdiv(i, a.magic_seq), c = i - y * CB;     // lanes along the columns: contiguous in T1
-        A[c * NP + fpad(a.off + y)] = t1[(size_t)y * N + kx0 + c];       // (odd sequence stride NP: the CB lanes hit CB banks)
+    for (int i0 = threadIdx.x; i0 < R * CB; i0 += 4 * (int)blockDim.x) {       // batches of 4 independent loads per lane
+        cx<T> v[4];
+        int yy[4], cc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * (int)blockDim.x < R * CB ? i0 + u * (int)blockDim.x : i0;
+            yy[u] = CB == 1 ? i : fastdiv(i, a.magic_seq);            // lanes along the columns: contiguous in T1
+            cc[u] = i - yy[u] * CB;
+            v[u] = t1[(size_t)yy[u] * N + kx0 + cc[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + u * (int)blockDim.x < R * CB)
+                A[cc[u] * NP + fpad(a.off + yy[u])] = v[u];          // (odd sequence stride NP: the CB lanes hit CB banks)
     }
     cx<T>* f = fft_lds<T>(A, B, a.plan, CB, twl, 0);
     cx<T>* g = (f == A) ? B : A;
