@@ -28,7 +28,7 @@ GEOMETRY = dict(diameter=8.0, nSubaperture=20, nPixelPerSubap=6, r0=0.13, L0=30.
                 windDirection=[72.0], fractionalR0=[1.0], altitude=[0.0], magnitude=8.0, opticalBand="I",
                 mechanicalCoupling=0.35, nModes=50, gainCL=0.5, leak=0.99)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-PMC_TRAFFIC = os.path.join(REPO, "profiles", "r01_f_pmc_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+PMC_TRAFFIC = os.path.join(REPO, "profiles", "r01_g_pmc_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
 
 
 def measured_traffic(kernel, n_envs):
