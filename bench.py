@@ -91,9 +91,10 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=256)
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--noise", action="store_true",
-                    help="WFS camera of the reference's Razor env (photon + dark + read-out noise, QE, FWC, 10-bit ADC: "
-                         "MAIN/OOPAOEnv/OOPAOEnvRazor.py:243-250, 333) instead of the ideal detector of the parity configuration")
+    ap.add_argument("--noise", nargs="?", const="razor", default="off", choices=["off", "photon", "razor"],
+                    help="WFS camera: off = the ideal detector of the parity configuration; photon = photon (Poisson) noise only, "
+                         "the reference envs' default (MAIN/OOPAOEnv/OOPAOEnv.py:379); razor = the Razor env's camera (photon + dark "
+                         "+ read-out noise, QE, FWC, 10-bit ADC: MAIN/OOPAOEnv/OOPAOEnvRazor.py:243-250, 333)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     args = ap.parse_args()
 
@@ -114,10 +115,12 @@ def main():
     env = BatchedAOEnv(n_envs=n_local, device=local, dtype=args.dtype, return_frame=True,
                        env_index_offset=rank * n_local)
     env.set_params(dict(GEOMETRY, nLoop=2 * (K + W) + 16), wfs_type="shackhartmann")
-    if args.noise:
+    if args.noise == "razor":
         cam = env.wfs.cam
         cam.sensor, cam.FWC, cam.bits, cam.QE, cam.darkCurrent, cam.integrationTime = "CMOS", 10000, 10, 0.56, 5, 1 / 500
         cam.photonNoise, cam.readoutNoise = True, 14
+    elif args.noise == "photon":
+        env.wfs.cam.photonNoise = True
     env.generate_new_phase_screen(17)              # env e of the job uses seed 17 + e
     env.dm.coefs = 0
     env.measure()
@@ -166,7 +169,8 @@ def main():
                                "(BASELINE.json configs[1])",
                    "envs_per_gpu": n_local, "envs_total": n_total, "resolution": env.R, "n_valid_act": env.nValidAct,
                    "n_signal": env.nSignal, "layers": env.param.nLayer, "controller": "leaky integrator, gain 0.5",
-                   "noise": "Razor camera: photon + dark + read-out noise, QE 0.56, FWC 1e4, 10-bit ADC" if args.noise else "off", "parallelism": f"env-shards x{world}, all-gather of episode returns"},
+                   "noise": {"razor": "Razor camera: photon + dark + read-out noise, QE 0.56, FWC 1e4, 10-bit ADC",
+                             "photon": "photon (Poisson) noise, Philox4x32-7 streams", "off": "off"}[args.noise], "parallelism": f"env-shards x{world}, all-gather of episode returns"},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(dom, n_local),
                      "algorithmic_bytes_per_launch": kbytes[dom] * n_local, "avg_launch_us": per_kernel[dom]["avg_us"]},

@@ -17,8 +17,10 @@ namespace ao {
 struct Philox {
     uint32_t c[4], k[2];
     __device__ inline void round() {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+        // one 32 x 32 -> 64 multiply per product (v_mad_u64_u32) instead of a mul-hi and a mul-lo: integer multiplies are quarter rate
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         const uint32_t n0 = hi1 ^ c[1] ^ k[0], n2 = hi0 ^ c[3] ^ k[1];
         c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
         k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
@@ -84,7 +86,7 @@ __device__ inline float poisson(float lam, PixelRng& g) {
         int k = 0;
         while (u > cdf && k < 200) {
             ++k;
-            p *= lam / (float)k;
+            p *= lam * __builtin_amdgcn_rcpf((float)k);              // 1 ulp reciprocal: the term of the series to 1e-7
             cdf += p;
         }
         return (float)k;
