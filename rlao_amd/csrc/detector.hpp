@@ -60,20 +60,16 @@ struct PixelRng {
     }
 };
 
-// log(k!) for integer-valued k >= 0: table below 16, Stirling's series (two correction terms, |error| < 2e-9) above.
+// log(k!) for integer-valued k >= 0.
 // (lgammaf costs ~10x more instructions, and the PTRS acceptance test below runs for every lit pixel of every frame.)
 __device__ inline float log_factorial(float k) {
-    if (k < 16.f) {
-        const float tab[16] = {0.f, 0.f, 0.693147181f, 1.791759469f, 3.17805383f, 4.787491743f, 6.579251212f, 8.525161361f,
-                               10.604602903f, 12.801827480f, 15.104412573f, 17.502307846f, 19.987214496f, 22.552163853f,
-                               25.191221183f, 27.899271384f};
-        float v = 0.f;
-#pragma unroll
-        for (int i = 2; i < 16; ++i) v = (k == (float)i) ? tab[i] : v;
-        return v;
-    }
-    const float r = 1.f / k;
-    return k * __logf(k) - k + 0.5f * __logf(6.283185307179586f * k) + r * (0.0833333333f - 0.00277777778f * r * r);
+    // k >= 4: Stirling's series with three correction terms, |error| < 2e-8;  k = 0..3 from a 4-entry select
+    const float kk = fmaxf(k, 4.f);
+    const float r = __builtin_amdgcn_rcpf(kk), r2 = r * r;
+    const float st = kk * __logf(kk) - kk + 0.5f * __logf(6.283185307179586f * kk) +
+                     r * (0.0833333333f + r2 * (-0.00277777778f + r2 * 0.000793650794f));
+    const float small = k < 2.f ? 0.f : (k < 3.f ? 0.693147181f : 1.791759469f);
+    return k < 4.f ? small : st;
 }
 
 // Poisson(lam): sequential inversion below 12 (exact, ~lam iterations), Hoermann's PTRS above (exact; the algorithm
@@ -91,23 +87,27 @@ __device__ inline float poisson(float lam, PixelRng& g) {
         }
         return (float)k;
     }
-    const float slam = sqrtf(lam), loglam = __logf(lam);
+    // (1-ulp hardware reciprocals / square root: an IEEE division expands to ~10 instructions, and the constants of the
+    //  hat function do not need the last bit)
+    const float slam = __builtin_amdgcn_sqrtf(lam), loglam = __logf(lam);
     const float b = 0.931f + 2.53f * slam, a = -0.059f + 0.02483f * b;
-    const float invalpha = 1.1239f + 1.1328f / (b - 3.4f), vr = 0.9277f - 3.6224f / (b - 2.f);
+    const float invalpha = 1.1239f + 1.1328f * __builtin_amdgcn_rcpf(b - 3.4f), vr = 0.9277f - 3.6224f * __builtin_amdgcn_rcpf(b - 2.f);
+    const float log_invalpha = __logf(invalpha);
     for (int it = 0; it < 64; ++it) {
         const float U = g.next() - 0.5f, V = g.next();
         const float us = 0.5f - fabsf(U);
-        const float kf = floorf((2.f * a / us + b) * U + lam + 0.43f);
+        const float rus = __builtin_amdgcn_rcpf(us);
+        const float kf = floorf((2.f * a * rus + b) * U + lam + 0.43f);
         if (us >= 0.07f && V <= vr) return kf;
         if (kf < 0.f || (us < 0.013f && V > us)) continue;
-        if (__logf(V) + __logf(invalpha) - __logf(a / (us * us) + b) <= -lam + kf * loglam - log_factorial(kf)) return kf;
+        if (__logf(V) + log_invalpha - __logf(a * rus * rus + b) <= -lam + kf * loglam - log_factorial(kf)) return kf;
     }
     return floorf(lam + 0.5f);
 }
 
 __device__ inline float gaussian(PixelRng& g) {
     const float u1 = g.next(), u2 = g.next();
-    return sqrtf(-2.f * __logf(u1)) * __cosf(6.283185307179586f * u2);
+    return __builtin_amdgcn_sqrtf(-2.f * __logf(u1)) * __cosf(6.283185307179586f * u2);
 }
 
 // photons in -> camera counts out
