@@ -230,10 +230,14 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
         const int n4 = (S * S) / 4;                              // env maps are 16-byte aligned when S*S % 4 == 0
         float lo = 3.0e38f, hi = -3.0e38f;
         if ((S * S) % 4 == 0) {
-            for (int i = tid; i < n4; i += 1024) {
-                const f32x4s v = *reinterpret_cast<const f32x4s*>(map + 4 * i);
+            for (int i0 = tid; i0 < n4; i0 += 4 * 1024) {           // 4 independent 16-byte loads per lane in flight
+                f32x4s v[4];
 #pragma unroll
-                for (int d = 0; d < 4; ++d) { lo = v[d] < lo ? v[d] : lo; hi = v[d] > hi ? v[d] : hi; }
+                for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4s*>(map + 4 * (i0 + 1024 * u < n4 ? i0 + 1024 * u : i0));
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) { lo = v[u][d] < lo ? v[u][d] : lo; hi = v[u][d] > hi ? v[u][d] : hi; }
             }
         } else {
             for (int i = tid; i < S * S; i += 1024) { const float v = map[i]; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
