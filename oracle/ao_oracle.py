@@ -340,7 +340,7 @@ class OracleAtmosphere:
 # --------------------------------------------------------------------------------------
 # Deformable mirror                                          (OOPAO/DeformableMirror.py)
 # --------------------------------------------------------------------------------------
-def dm_geometry(resolution, D, n_subap, mech_coupling=0.35, pitch=None, central_obstruction=0.0):
+def dm_geometry(resolution, D, n_subap, mech_coupling=0.35, pitch=None, central_obstruction=0.0, dense=True):
     """Fried-geometry Gaussian DM: valid mask, separable factors and dense IF matrix.
 
     valid-actuator rule :300-305; IF model :494-514 (zero mis-registration => separable).
@@ -358,6 +358,8 @@ def dm_geometry(resolution, D, n_subap, mech_coupling=0.35, pitch=None, central_
     c = (resolution / (nAct - 1)) / np.sqrt(2 * np.log(1.0 / mech_coupling))
     px = np.linspace(0, 1, resolution) * resolution
     g = np.exp(-((px[:, None] - u0[None, :]) ** 2) / (2 * c ** 2))          # [R, nAct]
+    if not dense:                                              # ELT size: the dense matrix is 9.6 GB
+        return dict(nAct=nAct, validAct=valid, gx=g, gy=g.copy(), modes=None)
     XX, YY = np.meshgrid(px, px)
     a = 1.0 / (2 * c ** 2)
     k = np.nonzero(valid)[0]
@@ -755,7 +757,7 @@ class OracleEnv:
                  r0=0.13, L0=30.0, windSpeed=(10.0,), windDirection=(72.0,), fractionalR0=(1.0,),
                  altitude=(0.0,), mech_coupling=0.35, m2c=None, n_modes=50, light_ratio=None,
                  threshold_cog=0.01, nLoop=10000, leak=0.99, gainCL=0.5, n_meas=6, wfs_type="sh", modulation=0.0,
-                 psf_centering=True, second_dm_nsub=None):
+                 psf_centering=True, second_dm_nsub=None, modal_cm=None):
         self.R, self.D, self.dt = resolution, diameter, dt
         self.leak, self.gainCL = leak, gainCL
         self.pupil = make_pupil(resolution)
@@ -770,6 +772,7 @@ class OracleEnv:
         self.dm_mask = dm["validAct"].reshape(self.nActuator, self.nActuator)
         self.xvalid, self.yvalid = np.nonzero(self.dm_mask)
         self.nValidAct = int(dm["validAct"].sum())
+        self.dm_blocks = [(0, self.nValidAct)]                   # every DM is calibrated by its own InteractionMatrix call
         if second_dm_nsub is not None:
             # a second DM chained behind the first, tel*dm1*dm2 (Telescope.py:533-544: every DM adds its OPD): one stacked
             # command vector [dm1 | dm2]; the actuator "image" holds both grids, dm1 top-left and dm2 bottom-right
@@ -782,6 +785,7 @@ class OracleEnv:
             mask[n1:, n1:] = dm2["validAct"].reshape(n2, n2)
             self.dm_mask = mask
             self.xvalid, self.yvalid = np.nonzero(mask)
+            self.dm_blocks = [(0, self.nValidAct), (self.nValidAct, int(mask.sum()))]
             self.nValidAct = int(mask.sum())
             self.gx = self.gy = None
         self.wfs_type = wfs_type
@@ -796,11 +800,18 @@ class OracleEnv:
             Z = zernike_modes(self.pupil, diameter, n_modes)
             m2c = np.linalg.pinv(self.dm_modes[self.pupil.reshape(-1)]) @ Z
         self.M2C = m2c[:, :n_modes]
-        self.imat = self.interaction_matrix(self.wavelength / 16, n_meas)
-        Mmod = calibration_vault_M(self.imat @ self.M2C)
+        self.n_meas = n_meas
+        if modal_cm is None:
+            self.imat = self.interaction_matrix(self.wavelength / 16, n_meas)
+            Mmod = calibration_vault_M(self.imat @ self.M2C)
+        else:                                                   # large geometries: the modal command matrix calib.M is handed
+            self.imat = None                                    # over (the tests pin it, and a few pokes, separately)
+            Mmod = np.asarray(modal_cm, dtype=float)
+        self.modal_cm = Mmod
         self.reconstructor = self.M2C @ Mmod                    # OOPAOEnv.py:381
         self.F = self.M2C @ np.linalg.pinv(self.M2C)            # :383
         self.coefs = np.zeros(self.nValidAct)
+        self.dm_prev = np.zeros(self.nValidAct)                 # OOPAOEnv.py:314: set once here, then only by step()
         self.total = np.zeros(nLoop)
         self.residual = np.zeros(nLoop)
         self.SR = []
@@ -821,34 +832,39 @@ class OracleEnv:
     def img_to_vec(self, a):
         return a[self.xvalid, self.yvalid]
 
+    def poke_signal(self, a, stroke):
+        """wfs.signal / stroke of one poked actuator on its own (Pyramid, or an SH measurement that shares no threshold)."""
+        cf = np.zeros(self.nValidAct)
+        cf[a] = stroke
+        return self.wfs.measure(self.dm_opd(cf) * self.pupil * TWO_PI / self.wavelength) / stroke
+
     def interaction_matrix(self, stroke, n_meas):
-        """Zonal push-only matrix D = signal(poke)/stroke, pokes measured in batches of n_meas
-        that share the centroid-threshold maximum (multi-wavefront branch, ShackHartmann.py:605-672)."""
+        """Zonal push-only matrix D = signal(poke)/stroke (InteractionMatrix.py:13-135, single_pass), one call per DM: the
+        pokes of a call are measured in batches of n_meas that share the centroid-threshold maximum (multi-wavefront
+        branch, ShackHartmann.py:605-672); the last batch of a call holds its n % n_meas last actuators (:72-78)."""
         nA = self.nValidAct
         D = np.zeros((self.wfs.nSignal, nA))
         if self.wfs_type != "sh":                                # Pyramid: the batched measurements are independent
             for a in range(nA):
-                cf = np.zeros(nA)
-                cf[a] = stroke
-                D[:, a] = self.wfs.measure(self.dm_opd(cf) * self.pupil * TWO_PI / self.wavelength) / stroke
+                D[:, a] = self.poke_signal(a, stroke)
             return D
-        k = 0
-        n_cycle = int(np.ceil(nA / n_meas))
-        n_extra = nA % n_meas
-        for c in range(n_cycle):
-            if c == n_cycle - 1 and n_extra != 0:
-                idx = list(range(nA - n_extra, nA))
-            else:
-                idx = list(range(c * n_meas, (c + 1) * n_meas))
-            phases = []
-            for a in idx:
-                cf = np.zeros(nA)
-                cf[a] = stroke
-                phases.append(self.dm_opd(cf) * TWO_PI / self.wavelength)   # phase_no_pupil
-            gmax = max(self.wfs.spots(ph)[self.wfs.valid_1d].max() for ph in phases)
-            for a, ph in zip(idx, phases):
-                D[:, a] = self.wfs.measure(ph, group_max=gmax) / stroke
-            k += 1
+        for lo, hi in self.dm_blocks:
+            n = hi - lo
+            n_cycle = int(np.ceil(n / n_meas))
+            n_extra = n % n_meas
+            for c in range(n_cycle):
+                if c == n_cycle - 1 and n_extra != 0:
+                    idx = list(range(hi - n_extra, hi))
+                else:
+                    idx = list(range(lo + c * n_meas, lo + (c + 1) * n_meas))
+                phases = []
+                for a in idx:
+                    cf = np.zeros(nA)
+                    cf[a] = stroke
+                    phases.append(self.dm_opd(cf) * TWO_PI / self.wavelength)   # phase_no_pupil
+                gmax = max(self.wfs.spots(ph)[self.wfs.valid_1d].max() for ph in phases)
+                for a, ph in zip(idx, phases):
+                    D[:, a] = self.wfs.measure(ph, group_max=gmax) / stroke
         return D
 
     def measure(self):
@@ -872,7 +888,8 @@ class OracleEnv:
         self.total[i] = np.std(self.atm.OPD[self.pupil]) * 1e9
         self.tel_OPD = (self.atm.OPD_no_pupil + self.dm_opd(self.coefs)) * self.pupil
         self.measure()
-        self.coefs = self.coefs * self.leak + a
+        self.coefs = self.dm_prev * self.leak + a               # OOPAOEnv.py:508-509: dm_prev, not dm.coefs
+        self.dm_prev = self.coefs.copy()
         obs = self.vec_to_img(-self.reconstructor @ self.wfs.signal) * 1e6
         self.residual[i] = np.std(self.tel_OPD[self.pupil]) * 1e9
         strehl = np.exp(-np.var(self.phase[self.pupil]))

@@ -51,6 +51,16 @@ CASES = {
     "papyrus_pyr": dict(R=120, nsub=20, D=1.52, r0=0.25, L0=10.0, ws=[20.0], wd=[72.0], frac=[1.0], alt=[0.0],
                         n_modes=50, steps=12, seeds=[0], gain=0.5, full_every=6, m2c_file=True, wfs="pyr", modulation=0,
                         centering=True),
+    # BASELINE.json configs[2] at its real size: 8 m, 40x40 Pyramid (R = 240, nRes = 528 = 16 * 3 * 11), unmodulated, the env's
+    # default (centred) mask, 50 Zernike modes as OOPAOEnv.set_params keeps (SURVEY.md 8c "R=240/40 sub Pyr single step")
+    "c3_pyr": dict(R=240, nsub=40, D=8.0, r0=0.13, L0=30.0, ws=[10.0], wd=[72.0], frac=[1.0], alt=[0.0],
+                   n_modes=50, steps=4, seeds=[17], gain=0.5, full_every=3, wfs="pyr", modulation=0, centering=True),
+    # BASELINE.json configs[4] per-env physics: 3 layers (the first three of papyrus_config.yaml's commented profile, Cn2
+    # renormalised) + two chained DMs (20x20 and 10x10 pitch, the second one altitude-conjugated at 5000 m:
+    # with fov = 0 it has the ground DM's grid, OOPAO/DeformableMirror.py:388-389), tel*dm1*dm2*wfs in closed loop
+    "c5_mcao": dict(R=120, nsub=20, D=8.0, r0=0.13, L0=30.0, ws=[10.0, 12.0, 11.0], wd=[0.0, 72.0, 144.0],
+                    frac=[0.45 / 0.65, 0.1 / 0.65, 0.1 / 0.65], alt=[0.0, 1000.0, 5000.0],
+                    n_modes=50, steps=12, seeds=[17], gain=0.5, full_every=6, second_nsub=10, second_alt=5000.0),
 }
 
 
@@ -68,6 +78,11 @@ def build(ref, c):
         nAct = c["nsub"] + 1
         dm = ref.DeformableMirror(telescope=tel, nSubap=c["nsub"], mechCoupling=0.35, coordinates=None,
                                   pitch=tel.D / nAct)
+        dm2 = None
+        if c.get("second_nsub"):
+            n2 = c["second_nsub"] + 1
+            dm2 = ref.DeformableMirror(telescope=tel, nSubap=c["second_nsub"], mechCoupling=0.35, coordinates=None,
+                                       pitch=tel.D / n2, altitude=c.get("second_alt"))
         tel.isPaired = False
         tel.resetOPD()
         if c.get("wfs", "sh") == "sh":
@@ -81,30 +96,80 @@ def build(ref, c):
         if c.get("m2c_file"):
             m2c = np.load(MANUAL_M2C)[:, :c["n_modes"]]                    # OOPAOEnv.py:260
         else:
-            # OOPAOEnv.py:258 / OOPAOEnvRazor.py:261 with the Noll basis restated in the oracle (aotools absent)
+            # OOPAOEnv.py:258 / OOPAOEnvRazor.py:261 with the Noll basis restated in the oracle (aotools absent);
+            # two DMs: the stacked influence matrix [dm1 | dm2]
             Z = O.zernike_modes(tel.pupil > 0, tel.D, c["n_modes"])
-            m2c = np.linalg.pinv(np.squeeze(dm.modes[tel.pupilLogical, :])) @ Z
+            modes = dm.modes if dm2 is None else np.hstack([dm.modes, dm2.modes])
+            m2c = np.linalg.pinv(np.squeeze(modes[tel.pupilLogical, :])) @ Z
+            del modes
         tel - atm
-        calib = ref.InteractionMatrix(ngs=ngs, atm=atm, tel=tel, dm=dm, wfs=wfs, M2C=np.eye(dm.nValidAct),
-                                      stroke=ngs.wavelength / 16, nMeasurements=6, noise="off", display=False,
-                                      single_pass=True)
-        vault = ref.CalibrationVault(calib.D @ m2c)
+        # every DM is calibrated by its own InteractionMatrix call (an un-paired telescope takes ONLY the last DM's OPD,
+        # OOPAO/DeformableMirror.py:474-476, so chained DMs cannot be poked in one call); D = [D1 | D2]
+        Ds = []
+        for d in ([dm] if dm2 is None else [dm, dm2]):
+            calib = ref.InteractionMatrix(ngs=ngs, atm=atm, tel=tel, dm=d, wfs=wfs, M2C=np.eye(d.nValidAct),
+                                          stroke=ngs.wavelength / 16, nMeasurements=6, noise="off", display=False,
+                                          single_pass=True)
+            Ds.append(np.asarray(calib.D))
+        Dfull = np.hstack(Ds)
+        vault = ref.CalibrationVault(Dfull @ m2c)
         tel.resetOPD()
         dm.coefs = 0
+        if dm2 is not None:
+            dm2.coefs = 0
         ngs * tel * dm * wfs
         atm.generateNewPhaseScreen(seed=10)
         tel + atm
     recon = m2c @ vault.M
     F = m2c @ np.linalg.pinv(m2c)
-    dm_mask = np.reshape(dm.validAct, (nAct, nAct))
+    if dm2 is None:
+        dm_mask = np.reshape(dm.validAct, (nAct, nAct))
+    else:                                 # actuator image of the pair: dm1's grid top-left, dm2's bottom-right (calib.CompositeDM)
+        n2 = dm2.nAct
+        dm_mask = np.zeros((nAct + n2, nAct + n2), bool)
+        dm_mask[:nAct, :nAct] = np.reshape(dm.validAct, (nAct, nAct))
+        dm_mask[nAct:, nAct:] = np.reshape(dm2.validAct, (n2, n2))
+        nAct = nAct + n2
     xv, yv = np.nonzero(dm_mask)
-    return dict(tel=tel, ngs=ngs, atm=atm, dm=dm, wfs=wfs, m2c=m2c, D=calib.D, recon=recon, F=F,
-                xvalid=xv, yvalid=yv, nAct=nAct)
+    return dict(tel=tel, ngs=ngs, atm=atm, dm=dm, dm2=dm2, wfs=wfs, m2c=m2c, D=Dfull, modal_cm=np.asarray(vault.M), recon=recon, F=F,
+                xvalid=xv, yvalid=yv, nAct=nAct, dm_mask=dm_mask)
 
 
-def run_episode(env, c, seed):
-    """mbrl.py:49-55 prologue + integrator closed loop through OOPAOEnv.step arithmetic."""
-    tel, atm, dm, wfs = env["tel"], env["atm"], env["dm"], env["wfs"]
+class _Coefs:
+    """dm.coefs of one mirror, or the stacked vector [dm1 | dm2] of two chained ones (bookkeeping only)."""
+
+    def __init__(self, dm, dm2=None):
+        self.dm, self.dm2 = dm, dm2
+        self.nValidAct = dm.nValidAct + (dm2.nValidAct if dm2 is not None else 0)
+
+    def set(self, v):
+        if self.dm2 is None:
+            self.dm.coefs = v
+        elif np.isscalar(v):
+            self.dm.coefs = v
+            self.dm2.coefs = v
+        else:
+            self.dm.coefs = np.asarray(v)[:self.dm.nValidAct]
+            self.dm2.coefs = np.asarray(v)[self.dm.nValidAct:]
+
+    def get(self):
+        if self.dm2 is None:
+            return np.asarray(self.dm.coefs).copy()
+        return np.concatenate([np.asarray(self.dm.coefs).reshape(-1), np.asarray(self.dm2.coefs).reshape(-1)])
+
+    def propagate(self, tel, wfs):
+        if self.dm2 is None:
+            tel * self.dm * wfs
+        else:
+            tel * self.dm * self.dm2 * wfs                        # paired telescope: every DM adds its OPD (Telescope.py:533-544)
+
+
+def run_episode(env, c, seed, dm_prev_in=None):
+    """mbrl.py:49-55 prologue + integrator closed loop through OOPAOEnv.step arithmetic.  dm_prev_in: the env's dm_prev as
+    the previous episode left it (the prologue's ``dm.coefs = 0`` does not clear it, OOPAOEnv.py:314, 508-509); None = a
+    fresh env (dm_prev = 0 from set_params)."""
+    tel, atm, wfs = env["tel"], env["atm"], env["wfs"]
+    dm = _Coefs(env["dm"], env.get("dm2"))
     nAct, xv, yv, recon = env["nAct"], env["xvalid"], env["yvalid"], env["recon"]
     leak = 0.99
 
@@ -115,9 +180,9 @@ def run_episode(env, c, seed):
 
     with RL.quiet():
         atm.generateNewPhaseScreen(seed)
-        dm.coefs = 0
-        tel * dm * wfs
-    dm_prev = dm.coefs.copy()
+        dm.set(0)
+        dm.propagate(tel, wfs)
+    dm_prev = dm.get() if dm_prev_in is None else np.asarray(dm_prev_in).copy()
     obs0 = vec_to_img(-np.matmul(recon, wfs.signal)) * 1e6          # reset_soft
     T = c["steps"]
     R = c["R"]
@@ -137,9 +202,9 @@ def run_episode(env, c, seed):
         total = np.std(tel.OPD[np.where(tel.pupil > 0)]) * 1e9       # :497
         opd_atm = tel.OPD.copy()
         with RL.quiet():
-            tel * dm * wfs                                           # :503
-        dm.coefs = (dm_prev * leak) + a                              # :508
-        dm_prev = dm.coefs.copy()
+            dm.propagate(tel, wfs)                                   # :503
+            dm.set((dm_prev * leak) + a)                             # :508
+        dm_prev = dm.get()
         obs = vec_to_img(-np.matmul(recon, wfs.signal)) * 1e6        # :517-518
         out["obs"][i] = obs
         out["reward"][i] = -1 * np.linalg.norm(obs)                  # :536
@@ -147,7 +212,7 @@ def run_episode(env, c, seed):
         out["total"][i] = total
         out["residual"][i] = np.std(tel.OPD[np.where(tel.pupil > 0)]) * 1e9           # :522
         out["signal"][i] = wfs.signal
-        out["coefs"][i] = dm.coefs
+        out["coefs"][i] = dm.get()
         for l in range(atm.nLayer):
             out["buff"][i, l] = getattr(atm, f"layer_{l + 1}").buff
         if i % c["full_every"] == 0 or i == T - 1:
@@ -159,6 +224,7 @@ def run_episode(env, c, seed):
     for k in ("opd_atm", "opd_res", "frame", "mapShift", "full_steps"):
         out[k] = np.asarray(out[k])
     assert opd_atm.shape == (R, R)
+    out["dm_prev_end"] = dm_prev
     return out
 
 
@@ -166,15 +232,29 @@ def make_case(ref, name):
     c = CASES[name]
     env = build(ref, c)
     tel, atm, dm, wfs = env["tel"], env["atm"], env["dm"], env["wfs"]
+    dm2 = env.get("dm2")
     L1 = atm.layer_1
+    big = env["D"].size > 400000          # interaction matrix beyond ~3 MB: keep columns / modal products instead
     consts = dict(
         cfg_R=c["R"], cfg_nsub=c["nsub"], cfg_D=c["D"], cfg_r0=c["r0"], cfg_L0=c["L0"],
         cfg_ws=np.array(c["ws"]), cfg_wd=np.array(c["wd"]), cfg_frac=np.array(c["frac"]), cfg_alt=np.array(c["alt"]),
         cfg_gain=c["gain"], cfg_n_modes=c["n_modes"], cfg_seeds=np.array(c["seeds"]),
         pupil=tel.pupil.astype(bool), wavelength=env["ngs"].wavelength, nPhoton=env["ngs"].nPhoton,
-        validAct=np.asarray(dm.validAct, bool),
-        m2c=env["m2c"], imat=env["D"], recon=env["recon"], F=env["F"],
-        xvalid=env["xvalid"], yvalid=env["yvalid"])
+        validAct=np.asarray(env["dm_mask"], bool).reshape(-1),
+        m2c=env["m2c"], F=env["F"], xvalid=env["xvalid"], yvalid=env["yvalid"])
+    if dm2 is not None:
+        consts.update(cfg_second_nsub=c["second_nsub"], cfg_second_alt=float(c.get("second_alt") or 0.0),
+                      validAct1=np.asarray(dm.validAct, bool), validAct2=np.asarray(dm2.validAct, bool))
+    if not big:
+        consts.update(imat=env["D"], recon=env["recon"])
+    else:
+        # three whole columns (first, middle, last poke), the modal interaction matrix D @ M2C and the modal command
+        # matrix calib.M = pinv_svd(D @ M2C): with the M2C above they determine the reconstructor M2C @ calib.M
+        cols = np.array([0, env["D"].shape[1] // 2, env["D"].shape[1] - 1])
+        rsq = np.random.RandomState(321)
+        pa = rsq.randn(env["D"].shape[1], 2)
+        consts.update(imat_cols_idx=cols, imat_cols=env["D"][:, cols], imat_probe_in=pa, imat_probe_out=env["D"] @ pa,
+                      imat_fro=np.linalg.norm(env["D"]), modal_imat=env["D"] @ env["m2c"], modal_cm=env["modal_cm"])
     if c.get("wfs", "sh") == "sh":
         consts.update(valid_subap=np.asarray(wfs.valid_subapertures, bool),
                       reference_slopes_maps=wfs.reference_slopes_maps, slopes_units=wfs.slopes_units)
@@ -193,6 +273,9 @@ def make_case(ref, name):
         consts.update(A_probe_in=pz, A_probe_out=L1.A @ pz, B_probe_in=px, B_probe_out=L1.B @ px,
                       A_fro=np.linalg.norm(L1.A), B_fro=np.linalg.norm(L1.B), A_shape=np.array(L1.A.shape),
                       modes_probe_in=pc, modes_probe_out=dm.modes @ pc, modes_fro=np.linalg.norm(dm.modes))
+        if dm2 is not None:
+            pc2 = rs.randn(dm2.nValidAct)
+            consts.update(modes2_probe_in=pc2, modes2_probe_out=dm2.modes @ pc2, modes2_fro=np.linalg.norm(dm2.modes))
     out = dict(consts)
     if c["R"] > 48:
         out.pop("F")                       # derived from the m2c input alone; keep the fixture small
@@ -206,8 +289,69 @@ def make_case(ref, name):
     np.savez_compressed(path, **out)
     s0 = c["seeds"][0]
     print(f"{name}: wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)  "
-          f"nValidAct={dm.nValidAct} nSignal={wfs.nSignal} "
-          f"strehl_last={out['s%d_strehl' % s0][-1]:.4f} res_last={out['s%d_residual' % s0][-1]:.1f} nm")
+          f"nValidAct={env['D'].shape[1]} nSignal={wfs.nSignal} "
+          f"strehl_last={out['s%d_strehl' % s0][-1]:.4f} res_last={out['s%d_residual' % s0][-1]:.1f} nm", flush=True)
+
+
+def make_two_episodes(ref):
+    """Two consecutive episodes of ONE env (tiny_sh geometry) with the trainers' prologue between them
+    (MAIN/PO4AO/mbrl.py:49-55: generateNewPhaseScreen, dm.coefs = 0, tel*dm*wfs, reset_soft): the env's dm_prev is NOT
+    cleared by that prologue (OOPAOEnv.py:314, 508-509), so step 0 of the second episode applies
+    leak * (last command of the first episode) + action."""
+    c = dict(CASES["tiny_sh"], steps=8)
+    env = build(ref, c)
+    ep1 = run_episode(env, c, 5)
+    ep2 = run_episode(env, c, 0, dm_prev_in=ep1["dm_prev_end"])
+    out = {"cfg_R": c["R"], "cfg_nsub": c["nsub"], "cfg_D": c["D"], "cfg_r0": c["r0"], "cfg_L0": c["L0"],
+           "cfg_ws": np.array(c["ws"]), "cfg_wd": np.array(c["wd"]), "cfg_frac": np.array(c["frac"]), "cfg_alt": np.array(c["alt"]),
+           "cfg_n_modes": c["n_modes"], "cfg_seeds": np.array([5, 0]), "m2c": env["m2c"]}
+    for tag, ep in (("e1_", ep1), ("e2_", ep2)):
+        for k in ("obs0", "actions", "obs", "reward", "strehl", "signal", "coefs", "residual", "total", "dm_prev_end"):
+            out[tag + k] = ep[k]
+    path = os.path.join(GOLD, "two_episodes.npz")
+    np.savez_compressed(path, **out)
+    print(f"two_episodes: wrote {path}; |dm_prev| carried into episode 2 = {np.abs(ep1['dm_prev_end']).max():.3e} m", flush=True)
+
+
+def c4_test_opd(R, seed=31):
+    """The wave-front of the ELT-size component fixture: smooth aberration + white roughness, metres (no pupil).  Also
+    imported by the tests, so that the input does not have to be stored."""
+    rs = np.random.RandomState(seed)
+    y, x = np.mgrid[0:R, 0:R] / float(R)
+    return (900e-9 * (x - 0.4) ** 2 - 700e-9 * x * y + 500e-9 * np.sin(7 * x + 3 * y) * (y - 0.5)
+            + 60e-9 * rs.normal(size=(R, R)))
+
+
+def make_c4_sh(ref):
+    """BASELINE.json configs[3] geometry (39 m, 80x80 Shack-Hartmann, R = 480, 81x81 actuators): the reference's own
+    Telescope / DeformableMirror / ShackHartmann on one fixed wave-front (c4_test_opd + a DM command): valid lenslets and
+    actuators, reference slopes, slope units, the residual OPD, wfs.signal and the camera frame of ONE measurement."""
+    R, ns, D = 480, 80, 39.0
+    with RL.quiet():
+        tel = ref.Telescope(resolution=R, diameter=D, samplingTime=1 / 500, centralObstruction=0, display_optical_path=False, fov=0)
+        ngs = ref.Source(optBand="I", magnitude=8, coordinates=[0, 0])
+        ngs * tel
+        dm = ref.DeformableMirror(telescope=tel, nSubap=ns, mechCoupling=0.35, coordinates=None, pitch=tel.D / (ns + 1))
+        wfs = ref.ShackHartmann(telescope=tel, nSubap=ns, lightRatio=0.5, is_geometric=False, shannon_sampling=True)
+    rs = np.random.RandomState(77)
+    coefs = rs.normal(size=dm.nValidAct) * 120e-9
+    opd_in = c4_test_opd(R)
+    with RL.quiet():
+        dm.coefs = coefs
+        tel.isPaired = True                                       # a paired telescope adds dm.OPD to OPD_no_pupil (DeformableMirror.py:469)
+        tel.OPD_no_pupil = opd_in.copy()
+        tel.OPD = opd_in * tel.pupil
+        tel * dm * wfs
+    frame = np.asarray(wfs.cam.frame, dtype=np.float64)
+    out = dict(cfg_R=R, cfg_nsub=ns, cfg_D=D, coefs=coefs, validAct=np.asarray(dm.validAct, bool),
+               valid_subap=np.asarray(wfs.valid_subapertures, bool), reference_slopes_maps=wfs.reference_slopes_maps,
+               slopes_units=wfs.slopes_units, signal=np.asarray(wfs.signal, dtype=np.float64),
+               opd_res_rows=np.asarray(tel.OPD, dtype=np.float64)[::16], frame_rows=frame[::8],
+               frame_sum=frame.sum(), frame_max=frame.max(), frame_sq=np.sqrt((frame ** 2).sum()),
+               frame_colsum=frame.sum(axis=0), frame_rowsum=frame.sum(axis=1))
+    path = os.path.join(GOLD, "c4_sh.npz")
+    np.savez_compressed(path, **out)
+    print(f"c4_sh: wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)  nValidAct={dm.nValidAct} nSignal={wfs.nSignal}", flush=True)
 
 
 def make_detector(ref):
@@ -319,6 +463,10 @@ def main():
         make_psf(ref)
     if args.only in (None, "two_dm"):
         make_two_dm(ref)
+    if args.only in (None, "two_episodes"):
+        make_two_episodes(ref)
+    if args.only in (None, "c4_sh"):
+        make_c4_sh(ref)
 
 
 if __name__ == "__main__":

@@ -11,13 +11,15 @@ import pytest
 
 from oracle import ao_oracle as O
 
-CASES = ["tiny_sh", "tiny_fastwind", "tiny_3layer", "small_sh", "c2_sh", "tiny_pyr", "tiny_pyr_mod", "papyrus_pyr"]
+CASES = ["tiny_sh", "tiny_fastwind", "tiny_3layer", "small_sh", "c2_sh", "tiny_pyr", "tiny_pyr_mod", "papyrus_pyr", "c5_mcao"]
 
 
-def _env_from_golden(g):
-    kw = {}
+def _env_from_golden(g, **extra):
+    kw = dict(extra)
     if "cfg_wfs" in g:
-        kw = dict(wfs_type="pyramid", modulation=float(g["cfg_modulation"]), psf_centering=bool(g["cfg_centering"]))
+        kw.update(wfs_type="pyramid", modulation=float(g["cfg_modulation"]), psf_centering=bool(g["cfg_centering"]))
+    if "cfg_second_nsub" in g:
+        kw.update(second_dm_nsub=int(g["cfg_second_nsub"]))
     return O.OracleEnv(resolution=int(g["cfg_R"]), diameter=float(g["cfg_D"]), n_subap=int(g["cfg_nsub"]),
                        r0=float(g["cfg_r0"]), L0=float(g["cfg_L0"]), windSpeed=list(g["cfg_ws"]),
                        windDirection=list(g["cfg_wd"]), fractionalR0=list(g["cfg_frac"]),
@@ -54,11 +56,15 @@ def test_constants(case):
         np.testing.assert_allclose(lay.A @ g["A_probe_in"], g["A_probe_out"], atol=1e-10)
         np.testing.assert_allclose(lay.B @ g["B_probe_in"], g["B_probe_out"], atol=1e-10)
         np.testing.assert_allclose(np.linalg.norm(lay.A), float(g["A_fro"]), rtol=1e-12)
-        np.testing.assert_allclose(env.dm_modes @ g["modes_probe_in"], g["modes_probe_out"], atol=1e-12)
+        a1 = len(g["modes_probe_in"])
+        np.testing.assert_allclose(env.dm_modes[:, :a1] @ g["modes_probe_in"], g["modes_probe_out"], atol=1e-12)
+        if "modes2_probe_in" in g:                              # second (altitude-conjugated, fov = 0) mirror of the pair
+            np.testing.assert_allclose(env.dm_modes[:, a1:] @ g["modes2_probe_in"], g["modes2_probe_out"], atol=1e-12)
     # separable DM factors reproduce the dense influence matrix
-    R = env.R
-    sep = np.einsum("yi,xj->yxij", env.gy, env.gx).reshape(R * R, -1)[:, env.dm_mask.reshape(-1)]
-    np.testing.assert_allclose(sep, env.dm_modes, atol=5e-16)
+    if env.gx is not None:
+        R = env.R
+        sep = np.einsum("yi,xj->yxij", env.gy, env.gx).reshape(R * R, -1)[:, env.dm_mask.reshape(-1)]
+        np.testing.assert_allclose(sep, env.dm_modes, atol=5e-16)
 
 
 def test_calibration(case):
@@ -74,6 +80,7 @@ def test_closed_loop_replay(case):
     name, g, env = case
     for seed in g["cfg_seeds"]:
         p = f"s{int(seed)}_"
+        env.dm_prev[:] = 0                                      # every recorded episode is the first one of a fresh env
         env.new_episode(int(seed))
         np.testing.assert_allclose(env.atm.layers[0].mapShift, g[p + "mapShift0"][0], atol=1e-12)
         np.testing.assert_allclose(env.reset_soft(), g[p + "obs0"], atol=1e-11)
@@ -96,6 +103,89 @@ def test_closed_loop_replay(case):
                 np.testing.assert_allclose(env.tel_OPD, g[p + "opd_res"][k], atol=1e-18)
                 np.testing.assert_allclose(frame, g[p + "frame"][k], atol=1e-8 * g[p + "frame"][k].max())
                 assert done is False
+
+
+def test_c3_pyramid_full_size(golden_dir):
+    """BASELINE configs[2] at its real size (8 m, 40x40 Pyramid, R = 240, nRes = 528 = 16 * 3 * 11, 1353 actuators): the oracle
+    against the reference's Pyramid / Atmosphere / DeformableMirror.  The 1353-poke interaction matrix is pinned through three
+    whole columns; the modal command matrix calib.M is then taken from the fixture (pinv of a 2608 x 50 matrix: checked too)."""
+    g = np.load(os.path.join(golden_dir, "c3_pyr.npz"))
+    env = _env_from_golden(g, modal_cm=g["modal_cm"])
+    assert env.R == 240 and env.wfs.nRes == 528 and env.nValidAct == 1353 and env.wfs.nSignal == 2608
+    assert np.array_equal(env.pupil, g["pupil"]) and np.array_equal(env.dm_mask.reshape(-1), g["validAct"])
+    assert np.array_equal(env.wfs.validI4Q, g["validI4Q"]) and env.wfs.nTheta == int(g["nTheta"])
+    np.testing.assert_allclose(env.wfs.referenceSignal_2D, g["referenceSignal_2D"], atol=1e-13)
+    np.testing.assert_allclose(env.wfs.m[::7, ::5], g["pyr_m"], atol=1e-13)
+    lay = env.atm.layers[0]
+    np.testing.assert_allclose(lay.A @ g["A_probe_in"], g["A_probe_out"], atol=1e-9)
+    np.testing.assert_allclose(lay.B @ g["B_probe_in"], g["B_probe_out"], atol=1e-9)
+    np.testing.assert_allclose(env.dm_modes @ g["modes_probe_in"], g["modes_probe_out"], atol=1e-12)
+    stroke = env.wavelength / 16
+    for k, a in enumerate(g["imat_cols_idx"]):
+        col = g["imat_cols"][:, k]
+        np.testing.assert_allclose(env.poke_signal(int(a), stroke), col, atol=1e-12 * np.abs(g["imat_cols"]).max())
+    np.testing.assert_allclose(O.calibration_vault_M(g["modal_imat"]), g["modal_cm"], atol=1e-9 * np.abs(g["modal_cm"]).max())
+    p = "s17_"
+    env.new_episode(17)
+    np.testing.assert_allclose(env.atm.layers[0].mapShift, g[p + "mapShift0"][0], atol=1e-12)
+    np.testing.assert_allclose(env.reset_soft(), g[p + "obs0"], atol=1e-10)
+    full = {int(s): k for k, s in enumerate(g[p + "full_steps"])}
+    for i, act in enumerate(g[p + "actions"]):
+        obs, frame, rew, sr, done, info = env.step(i, act)
+        np.testing.assert_allclose(env.wfs.signal, g[p + "signal"][i], atol=1e-10)
+        np.testing.assert_allclose(obs, g[p + "obs"][i], atol=1e-9)
+        np.testing.assert_allclose(rew, g[p + "reward"][i], atol=1e-9)
+        np.testing.assert_allclose(sr, g[p + "strehl"][i], atol=1e-12)
+        np.testing.assert_allclose(env.residual[i], g[p + "residual"][i], atol=1e-9)
+        np.testing.assert_allclose(env.coefs, g[p + "coefs"][i], atol=1e-18)
+        if i in full:
+            k = full[i]
+            np.testing.assert_allclose(env.tel_OPD, g[p + "opd_res"][k], atol=1e-18)
+            np.testing.assert_allclose(frame, g[p + "frame"][k], atol=1e-8 * g[p + "frame"][k].max())
+
+
+def test_c4_elt_shack_hartmann_measurement(golden_dir):
+    """BASELINE configs[3] geometry (39 m, 80x80 lenslets, R = 480, 5209 actuators): one tel*dm*wfs of the reference on a fixed
+    wave-front against the oracle's DM and Shack-Hartmann."""
+    from oracle.make_goldens import c4_test_opd
+    g = np.load(os.path.join(golden_dir, "c4_sh.npz"))
+    R, ns, D = int(g["cfg_R"]), int(g["cfg_nsub"]), float(g["cfg_D"])
+    pupil = O.make_pupil(R)
+    wl, n_photon = O.source_photometry("I", 8.0)
+    flux = pupil.astype(float) * n_photon * (1 / 500) * (D / R) ** 2
+    dm = O.dm_geometry(R, D, ns, 0.35, pitch=D / (ns + 1), dense=False)
+    assert np.array_equal(dm["validAct"], g["validAct"])
+    wfs = O.OracleSH(ns, R, D, pupil, wl, flux)
+    assert np.array_equal(wfs.valid_2d, g["valid_subap"])
+    np.testing.assert_allclose(wfs.reference_slopes_maps, g["reference_slopes_maps"], atol=1e-13)
+    np.testing.assert_allclose(wfs.slopes_units, float(g["slopes_units"]), rtol=1e-11)
+    cimg = np.zeros((ns + 1) ** 2)
+    cimg[dm["validAct"]] = g["coefs"]
+    dm_opd = dm["gy"] @ cimg.reshape(ns + 1, ns + 1) @ dm["gx"].T           # separable form of modes @ coefs
+    opd = (c4_test_opd(R) + dm_opd) * pupil
+    np.testing.assert_allclose(opd[::16], g["opd_res_rows"], atol=1e-18)
+    sig = wfs.measure(opd * 2 * np.pi / wl)
+    np.testing.assert_allclose(sig, g["signal"], atol=1e-10)
+    np.testing.assert_allclose(wfs.frame[::8], g["frame_rows"], atol=1e-8 * float(g["frame_max"]))
+    np.testing.assert_allclose(wfs.frame.sum(axis=0), g["frame_colsum"], rtol=1e-10)
+    np.testing.assert_allclose(wfs.frame.sum(axis=1), g["frame_rowsum"], rtol=1e-10)
+
+
+def test_second_episode_keeps_dm_prev(golden_dir):
+    """The trainers' episode prologue (MAIN/PO4AO/mbrl.py:49-55) zeroes dm.coefs but not the env's dm_prev
+    (MAIN/OOPAOEnv/OOPAOEnv.py:314, 508-509): step 0 of the next episode applies leak * (last command) + action."""
+    g = np.load(os.path.join(golden_dir, "two_episodes.npz"))
+    env = _env_from_golden(g)
+    for tag, seed in (("e1_", 5), ("e2_", 0)):
+        env.new_episode(seed)
+        np.testing.assert_allclose(env.reset_soft(), g[tag + "obs0"], atol=1e-11)
+        for i, act in enumerate(g[tag + "actions"]):
+            obs, _, rew, sr, _, _ = env.step(i, act)
+            np.testing.assert_allclose(obs, g[tag + "obs"][i], atol=1e-10)
+            np.testing.assert_allclose(env.coefs, g[tag + "coefs"][i], atol=1e-18)
+            np.testing.assert_allclose(sr, g[tag + "strehl"][i], atol=1e-12)
+        np.testing.assert_allclose(env.dm_prev, g[tag + "dm_prev_end"], atol=1e-18)
+    assert np.abs(g["e2_coefs"][0]).max() > 1e-8                  # the carried command is really there
 
 
 def test_detector_matches_reference(golden_dir):
