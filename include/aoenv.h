@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define AOENV_ABI_VERSION 3
+#define AOENV_ABI_VERSION 4
 
 enum { AOENV_F32 = 0, AOENV_F64 = 1 };
 enum { AOENV_WFS_SH = 0, AOENV_WFS_PYRAMID = 1 };
@@ -112,6 +112,10 @@ enum AoBuf {
     AOENV_B_MT_STATE,        /* [n_layer][n_env][625] uint32 (whatever the env dtype): the 624 MT19937 state words of
                                 the layer's ring RandomState and its position (OOPAO/Atmosphere.py:201, 308)         */
     AOENV_B_COUNTERS,        /* [4] uint32: frame counter of the camera noise streams, 3 reserved                 */
+    AOENV_B_DM_PREV,         /* [n_env][A]     env.dm_prev: the leaky integrator's state.  aoenv_step computes
+                                dm.coefs = dm_prev * leak + action and copies it back to dm_prev; aoenv_set_coefs (dm.coefs = ...
+                                from outside) leaves it alone, as in the reference (MAIN/OOPAOEnv/OOPAOEnv.py:314, 508-509), so
+                                the trainers' episode prologue `env.dm.coefs = 0` (MAIN/PO4AO/mbrl.py:50) does not clear it */
     AOENV_B_COUNT
 };
 
@@ -158,7 +162,7 @@ int aoenv_new_screens_device(AoEnv* env, const uint32_t* h_screen_seeds, const u
 int aoenv_set_atm_opd(AoEnv* env, const double* h_opd, void* stream);
 
 /* Replaces: dm.coefs = v (OOPAO/DeformableMirror.py:534-570).  h_coefs [n_env][A] float64 or NULL for
- * dm.coefs = 0 (MAIN/PO4AO/mbrl.py:50). */
+ * dm.coefs = 0 (MAIN/PO4AO/mbrl.py:50).  env.dm_prev (AOENV_B_DM_PREV) is not touched. */
 int aoenv_set_coefs(AoEnv* env, const double* h_coefs, void* stream);
 
 /* Replaces: tel*dm*wfs with no atmosphere update (MAIN/PO4AO/mbrl.py:52; OOPAO/Telescope.py:533-544,
@@ -176,7 +180,7 @@ int aoenv_reset_soft(AoEnv* env, void* d_obs, void* stream);
  *   d_frame  [n_env][cam][cam] or NULL  out: wfs.cam.frame (Papyrus 6-tuple) / NULL (Razor 5-tuple)
  *   d_reward [n_env]  out: -||obs||_2        d_strehl [n_env]  out: exp(-var(phase[pupil]))
  * Order of effects as in the reference: turbulence advances, the WFS sees the command latched by the
- * previous call, then dm.coefs <- leak * dm.coefs + 1e-6 * img_to_vec(action). */
+ * previous call, then dm.coefs <- leak * dm_prev + 1e-6 * img_to_vec(action) and dm_prev <- dm.coefs. */
 int aoenv_step(AoEnv* env, int i, const void* d_action, void* d_obs, void* d_frame, void* d_reward,
                void* d_strehl, void* stream);
 
@@ -196,7 +200,9 @@ int aoenv_compute_psf(AoEnv* env, int zero_padding, void* d_psf, void* stream);
  * OOPAOEnvRazor.py:243-250, 333).  The frame of every measurement then goes through integrate() + readout()
  * (Detector.py:232-301) before the slopes are computed.  The reference seeds its noise generators from the wall clock;
  * here every pixel of every frame draws from a counter-based stream keyed by `seed` and indexed by (pixel, env_index_offset
- * + env, frame number): reproducible, and the same for an env wherever it sits in a batch.  NULL = ideal detector. */
+ * + env, frame number): reproducible, and the same for an env wherever it sits in a batch.  NULL = ideal detector.
+ * The frame number keeps counting across calls (a camera setting changed in mid-run does not replay earlier noise frames); it
+ * restarts at 0 only when `seed` changes, and it is part of the checkpoint (AOENV_B_COUNTERS).  Work is enqueued on `stream`. */
 typedef struct AoDetector {
     int32_t photon_noise;    /* cam.photonNoise */
     int32_t bits;            /* ADC bits, 0 = None (needs fwc > 0 when set) */
@@ -209,7 +215,7 @@ typedef struct AoDetector {
     double  readout_noise;   /* cam.readoutNoise [e- rms] */
     uint64_t seed;
 } AoDetector;
-int aoenv_set_detector(AoEnv* env, const AoDetector* cfg);
+int aoenv_set_detector(AoEnv* env, const AoDetector* cfg, void* stream);
 
 /* Episode return on the device (the sum of rewards the trainers accumulate on the host, MAIN/PO4AO/mbrl.py:64-89):
  * d_return [n_env] is a caller-owned device buffer of the env dtype; every aoenv_step / integrator step adds its reward
@@ -245,6 +251,8 @@ enum AoOption {
                                  tile of the separate phase kernel: float32 shards Gy.C on the matrix cores (MFMA operand layout),
                                  float64 shards the scattered command image (always on above 1024 actuators: ELT-size DMs);
                                  0 (default below): every tile workgroup does it itself */
+    AOENV_OPT_FACTORED_RECON = 8, /* 1 (default): with AOENV_C_RECON_FACTORS uploaded, the batched (non-fused) reconstruction is the
+                                 chained product v = M2C (M s) instead of the dense reconstructor; 0: dense */
     AOENV_OPT_FAST_TRIG = 2  /* 1 (default): v_sin/v_cos after Cody-Waite reduction in the float32 SH kernel; 0: sincosf */
 };
 int aoenv_set_option(AoEnv* env, int option, int value);

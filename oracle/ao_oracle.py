@@ -396,6 +396,7 @@ class OracleSH:
         self.reference_slopes_maps = np.zeros((2 * n_subap, n_subap))
         self.slopes_units = 1.0
         self.frame = np.zeros((self.cam_res, self.cam_res))
+        self.cam = None                                         # wfs.cam: a Detector, or None = ideal (set after the calibration)
         self._calibrate(D)
 
     def _tiles(self, img):
@@ -421,6 +422,9 @@ class OracleSH:
         blocks = np.zeros((s * s, p, p))
         blocks[self.valid_1d] = I
         frame[:] = blocks.reshape(s, s, p, p).transpose(0, 2, 1, 3).reshape(s * p, s * p)   # :349-353
+        if self.cam is not None:                                # self*self.cam then split_camera_frame (:576, :355-362)
+            frame = self.cam.integrate(frame)
+            I = frame.reshape(s, p, s, p).transpose(0, 2, 1, 3).reshape(s * s, p, p)[self.valid_1d]
         self.frame = frame                                      # noise-free detector == identity
         im = I.copy()
         mx = im.max() if group_max is None else group_max

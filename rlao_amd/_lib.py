@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AOENV_LIB") or os.path.join(_HERE, "csrc", "libaoenv.so")   # AOENV_LIB: A/B kernel builds
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 F32, F64 = 0, 1
 WFS_SH, WFS_PYRAMID = 0, 1
 
@@ -17,10 +17,11 @@ WFS_SH, WFS_PYRAMID = 0, 1
  C_SH_SUBAP_IDX, C_SH_REF, C_WFS_UNITS, C_RECON, C_PYR_MASK, C_PYR_TT, C_RECON_FACTORS) = range(17)
 # enum AoBuf
 (B_SCREEN, B_OPD_ATM, B_COEFS, B_PHASE, B_FRAME, B_SIGNAL, B_TOTAL, B_RESIDUAL, B_WFS_MAX, B_XI, B_MT_STATE,
- B_COUNTERS) = range(12)
+ B_COUNTERS, B_DM_PREV) = range(13)
 
 
-OPT_FAST_WFS, OPT_MFMA_GEMM, OPT_FAST_TRIG, OPT_STORE_ATM_OPD, OPT_FUSED_TAIL, OPT_FUSED_STEP, OPT_DEFER_RING, OPT_COEFS_IMAGE = 0, 1, 2, 3, 4, 5, 6, 7
+(OPT_FAST_WFS, OPT_MFMA_GEMM, OPT_FAST_TRIG, OPT_STORE_ATM_OPD, OPT_FUSED_TAIL, OPT_FUSED_STEP, OPT_DEFER_RING, OPT_COEFS_IMAGE,
+ OPT_FACTORED_RECON) = range(9)
 KERNEL_NAMES = ("ring_prepare", "mt_normal", "gemm_ring", "ring_scatter", "phase", "sh_spots", "sh_centroid",
                 "gemm_recon", "recon_finish", "pyramid", "sh_tail", "env_step")
 
@@ -59,7 +60,7 @@ EXPORTS = {
     "aoenv_run_integrator": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p]),
     "aoenv_compute_psf": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
-    "aoenv_set_detector": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "aoenv_set_detector": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "aoenv_set_return_accumulator": (C.c_int, [C.c_void_p, C.c_void_p]),
     "aoenv_buffer": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "aoenv_download": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -77,7 +77,7 @@ template <typename T>
 int launch_minmax(const T* maps, T* minmax, int n_env, int S, hipStream_t st);
 int gemm_splits(int M, int N, int K);
 int launch_gemm_nt_mfma(const float* X, const float* W, float* Cpart, int M, int N, int K, int ldx, int ldw, int splits,
-                        hipStream_t st);
+                        hipStream_t st, int xsplits = 1, size_t xslab = 0);
 template <typename T>
 int launch_gemm_nt(const T* X, const T* W, T* C, int M, int N, int K, int ldx, int ldw, int ldc, hipStream_t st);
 
@@ -156,7 +156,9 @@ struct FinishArgs {
     int splits;
     const int* act_idx;      // [A]
     const T* action;         // [E][nAct^2] or null (gain_from_obs != 0)
-    T* coefs;                // [E][A]
+    T* coefs;                // [E][A]   dm.coefs
+    T* dm_prev;              // [E][A]   env.dm_prev: the integrator's state (MAIN/OOPAOEnv/OOPAOEnv.py:314, 508-509), which
+                             //          `dm.coefs = ...` from outside does not touch
     T* obs;                  // [E][nAct^2]
     T* reward;               // [E] or null
     T* ret;                  // [E] or null: episode return accumulator, += reward every step

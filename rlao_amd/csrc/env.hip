@@ -66,6 +66,7 @@ struct AoEnv {
     uint8_t* pupil = nullptr;
     void* opd_atm = nullptr;
     void* coefs = nullptr;
+    void* dm_prev = nullptr;                // [E][A] env.dm_prev, the integrator state (not touched by aoenv_set_coefs)
     float* dm_rows = nullptr;               // [E][Rpad128][4][ga_stride] Gy C per env (float32; k_dm_rows), the same switch
     void* coefs_img = nullptr;              // [E][nAct^2] command images for the phase kernels of large DMs (A > 1024)
     void* phase = nullptr;
@@ -94,6 +95,10 @@ struct AoEnv {
     void* recon = nullptr;                  // [A][nSig]
     void* fac_m = nullptr;                  // [K][nSig] modal command matrix calib.M          (AOENV_C_RECON_FACTORS)
     void* fac_m2c_t = nullptr;              // [K][A]    transposed M2C
+    void* fac_m2c = nullptr;                // [A][Kp]   M2C, rows zero padded to Kp = n_modes rounded up to 4 (16-byte rows)
+    void* tbuf = nullptr;                   // [splits][E][Kp] modal coefficients t = M s of the factored reconstruction
+    size_t fac_cap = 0;                     // modes the two buffers above are sized for
+    bool use_factored_recon = true;         // aoenv_set_option(AOENV_OPT_FACTORED_RECON)
     int n_modes = 0;
     // Pyramid
     void* pyr_mask = nullptr;               // [N*N][2]
@@ -105,6 +110,7 @@ struct AoEnv {
     int pyr_chunk = 1;
     void* vbuf = nullptr;                   // [E][A]
     DetectorCfg det{};                      // aoenv_set_detector(); det.active = 0: ideal camera
+    bool det_seeded = false;                // a seed has been set: the frame counter survives later aoenv_set_detector calls
     void* ret_acc = nullptr;                // caller-owned [E] episode-return accumulator (aoenv_set_return_accumulator)
     std::vector<void*> allocs;
     // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
@@ -422,6 +428,7 @@ FinishArgs<T> finish_args(AoEnv* env, const T* d_action, T* d_obs, T* d_reward, 
     fa.act_idx = env->act_idx;
     fa.action = d_action;
     fa.coefs = env->as<T>(env->coefs);
+    fa.dm_prev = env->as<T>(env->dm_prev);
     fa.obs = d_obs;
     fa.reward = d_reward;
     fa.ret = env->as<T>(env->ret_acc);
@@ -442,14 +449,40 @@ FinishArgs<T> finish_args(AoEnv* env, const T* d_action, T* d_obs, T* d_reward, 
     return fa;
 }
 
+// v = R s.  With the factors of the reconstructor on the device (R = M2C calib.M, MAIN/OOPAOEnv/OOPAOEnv.py:295, 381) the
+// product is chained, t = M s then v = M2C t: K (nSig + A) multiply-adds and bytes per env instead of A nSig -- 11x fewer at the
+// ELT size (A = 5209, nSig = 10048, K = 300: 209 MB of dense reconstructor streamed per step), 4.5x at 40x40 Pyramid size.
+template <typename T>
+int recon_product(AoEnv* env, int* splits, hipStream_t st) {
+    const int Kp = (env->n_modes + 3) & ~3;
+    if (env->n_modes > 0 && env->use_factored_recon && env->fac_m2c && env->tbuf &&
+        (size_t)Kp * (env->nSig + env->A) < (size_t)env->A * env->nSig) {
+        T* t = env->as<T>(env->tbuf);
+        if constexpr (std::is_same<T, float>::value) {
+            if (env->use_mfma) {
+                const int s1 = gemm_splits(env->E, Kp, env->nSig);
+                AO_TRY(launch_gemm_nt_mfma(env->as<float>(env->signal), env->as<float>(env->fac_m), t, env->E, Kp, env->nSig, env->nSig,
+                                           env->nSig, s1, st));
+                *splits = gemm_splits(env->E, env->A, Kp);
+                return launch_gemm_nt_mfma(t, env->as<float>(env->fac_m2c), env->as<float>(env->vbuf), env->E, env->A, Kp, Kp, Kp, *splits,
+                                           st, s1, (size_t)env->E * Kp);
+            }
+        }
+        *splits = 1;
+        AO_TRY(launch_gemm_nt<T>(env->as<T>(env->signal), env->as<T>(env->fac_m), t, env->E, Kp, env->nSig, env->nSig, env->nSig, Kp, st));
+        return launch_gemm_nt<T>(t, env->as<T>(env->fac_m2c), env->as<T>(env->vbuf), env->E, env->A, Kp, Kp, Kp, env->A, st);
+    }
+    return gemm_dispatch<T>(env, env->as<T>(env->signal), env->as<T>(env->recon), env->as<T>(env->vbuf), env->E, env->A, env->nSig,
+                            splits, st);
+}
+
 template <typename T>
 int run_recon(AoEnv* env, const T* d_action, T* d_obs, T* d_reward, T* d_strehl, int telemetry_index, int integrate,
               double gain, hipStream_t st) {
     int splits = 1;
     {
         AO_PROF(env, GEMM_RECON, st);
-        AO_TRY(gemm_dispatch<T>(env, env->as<T>(env->signal), env->as<T>(env->recon), env->as<T>(env->vbuf), env->E,
-                                env->A, env->nSig, &splits, st));
+        AO_TRY(recon_product<T>(env, &splits, st));
     }
     {
         FinishArgs<T> fa = finish_args<T>(env, d_action, d_obs, d_reward, d_strehl, telemetry_index, integrate, gain, splits);
@@ -643,17 +676,31 @@ int buf_info(AoEnv* env, int which, BufInfo* b) {
         case AOENV_B_XI: *b = {env->zx, E * env->K * z}; return 0;
         case AOENV_B_MT_STATE: *b = {nullptr, (size_t)env->L * E * (kMtN + 1) * 4}; return 0;     // packed on the host
         case AOENV_B_COUNTERS: *b = {nullptr, 16}; return 0;
+        case AOENV_B_DM_PREV: *b = {env->dm_prev, E * env->A * z}; return 0;
         default: return fail("unknown buffer id %d", which);
     }
 }
 
 }  // namespace
 
-#define AO_CHECK_ENV(env)                         \
-    do {                                          \
-        if (!(env)) return fail("null AoEnv");    \
-        AO_HIP(hipSetDevice((env)->device));      \
-    } while (0)
+// Every entry point runs on the env's device and hands the calling thread's current device back on return: PyTorch shares
+// this runtime, and an env on device k must not redirect the caller's later allocations and launches to k.
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = prev == device || hipSetDevice(device) == hipSuccess;
+        if (prev == device) prev = -1;                               // nothing to restore
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define AO_CHECK_ENV(env)                                                             \
+    if (!(env)) return fail("null AoEnv");                                            \
+    DeviceGuard ao_device_guard((env)->device);                                       \
+    if (!ao_device_guard.ok) return fail("hipSetDevice(%d) failed", (env)->device)
 #define AO_DISPATCH(env, fn, ...) ((env)->c.dtype == AOENV_F32 ? fn<float>(__VA_ARGS__) : fn<double>(__VA_ARGS__))
 
 extern "C" {
@@ -685,7 +732,8 @@ int aoenv_create(const AoCfg* cfg, int device, AoEnv** out) {
     int ndev = 0;
     AO_HIP(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail("device %d not in [0, %d)", device, ndev);
-    AO_HIP(hipSetDevice(device));
+    DeviceGuard ao_device_guard(device);
+    if (!ao_device_guard.ok) return fail("hipSetDevice(%d) failed", device);
 
     AoEnv* e = new (std::nothrow) AoEnv();
     if (!e) return fail("out of host memory");
@@ -721,6 +769,7 @@ int aoenv_create(const AoCfg* cfg, int device, AoEnv** out) {
     A_((void**)&e->pupil, R2);
     A_(&e->opd_atm, E * R2 * z);
     A_(&e->coefs, E * e->A * z);
+    A_(&e->dm_prev, E * e->A * z);                                 // self.dm_prev = self.dm.coefs.copy() = 0 (OOPAOEnv.py:313-314)
     A_(&e->phase, E * R2 * z);
     A_(&e->scal, E * 4 * z);
     e->n_tiles = phase_tiles(e->R, e->nAct, e->esz);
@@ -787,7 +836,7 @@ int aoenv_create(const AoCfg* cfg, int device, AoEnv** out) {
 
 int aoenv_destroy(AoEnv* env) {
     if (!env) return 0;
-    (void)hipSetDevice(env->device);
+    DeviceGuard ao_device_guard(env->device);
     for (auto& e : env->prof_ev) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (void* p : env->allocs) (void)hipFree(p);
     delete env;
@@ -915,6 +964,19 @@ int aoenv_upload(AoEnv* env, int kind, const void* h, size_t bytes) {
             for (int a = 0; a < env->A; ++a)
                 for (int k = 0; k < K; ++k) t[(size_t)k * env->A + a] = m2c[(size_t)a * K + k];
             AO_TRY(upload_real(env, env->fac_m2c_t, t.data(), t.size()));
+            // the same factors for the batched (non-fused) reconstruction: M with zero rows up to Kp, M2C as [A][Kp]
+            const int Kp = (K + 3) & ~3;
+            if ((size_t)Kp > env->fac_cap) {
+                AO_TRY(dmalloc(env, &env->fac_m2c, (size_t)env->A * Kp * env->esz));
+                AO_TRY(dmalloc(env, &env->tbuf, (size_t)kMaxSplits * env->E * Kp * env->esz));
+                env->fac_cap = (size_t)Kp;
+            }
+            if (Kp > K && Kp <= kMaxModes)
+                AO_HIP(hipMemset(static_cast<char*>(env->fac_m) + (size_t)K * env->nSig * env->esz, 0, (size_t)(Kp - K) * env->nSig * env->esz));
+            std::vector<double> mp((size_t)env->A * Kp, 0.0);
+            for (int a = 0; a < env->A; ++a)
+                for (int k = 0; k < K; ++k) mp[(size_t)a * Kp + k] = m2c[(size_t)a * K + k];
+            AO_TRY(upload_real(env, env->fac_m2c, mp.data(), mp.size()));
             env->n_modes = K;
             break;
         }
@@ -1227,8 +1289,9 @@ int aoenv_compute_psf(AoEnv* env, int zero_padding, void* d_psf, void* stream) {
                                      : compute_psf_t<double>(env, zero_padding, d_psf, st);
 }
 
-int aoenv_set_detector(AoEnv* env, const AoDetector* cfg) {
+int aoenv_set_detector(AoEnv* env, const AoDetector* cfg, void* stream) {
     AO_CHECK_ENV(env);
+    hipStream_t st = static_cast<hipStream_t>(stream);
     DetectorCfg d{};
     if (cfg) {
         if (cfg->bits < 0 || cfg->bits > 24) return fail("detector: bits %d outside [0, 24]", cfg->bits);
@@ -1247,13 +1310,20 @@ int aoenv_set_detector(AoEnv* env, const AoDetector* cfg) {
         d.seed_lo = (uint32_t)(cfg->seed & 0xffffffffu);
         d.seed_hi = (uint32_t)(cfg->seed >> 32);
         d.env_offset = (uint32_t)cfg->env_index_offset;
-        d.frame_counter = 0;
+        // the noise streams keep counting frames across camera changes: only a new seed starts them again
+        d.frame_counter = (env->det_seeded && env->det.seed_lo == d.seed_lo && env->det.seed_hi == d.seed_hi) ? env->det.frame_counter : 0;
         // identity settings are the ideal camera: keep the fast paths
         if (!d.photon_noise && d.bits == 0 && d.qe == 1.f && d.dark_e == 0.f && d.fwc == 0.f && d.gain == 1.f && d.readout_noise == 0.f)
             d.active = 0;
     }
     if (env->det.active && !d.active)                              // no stale noise outside the valid lenslets
-        AO_HIP(hipMemset(env->frame, 0, (size_t)env->E * env->c.cam_res * env->c.cam_res * env->esz));
+        AO_HIP(hipMemsetAsync(env->frame, 0, (size_t)env->E * env->c.cam_res * env->c.cam_res * env->esz, st));
+    if (!cfg) {                                                    // ideal detector: the stream position and its seed are kept
+        d.seed_lo = env->det.seed_lo; d.seed_hi = env->det.seed_hi; d.frame_counter = env->det.frame_counter;
+        d.env_offset = env->det.env_offset;
+    } else {
+        env->det_seeded = true;
+    }
     env->det = d;
     return 0;
 }
@@ -1402,6 +1472,7 @@ int aoenv_set_option(AoEnv* env, int option, int value) {
         case AOENV_OPT_FUSED_TAIL: env->use_fused_tail = value != 0; return 0;
         case AOENV_OPT_FUSED_STEP: env->use_fused_step = value != 0; return 0;
         case AOENV_OPT_DEFER_RING: env->defer_ring = value != 0; return 0;
+        case AOENV_OPT_FACTORED_RECON: env->use_factored_recon = value != 0; return 0;
         case AOENV_OPT_COEFS_IMAGE:
             if (value) AO_TRY(alloc_dm_rows(env));
             env->use_coefs_img = value != 0;
@@ -1435,7 +1506,8 @@ int aoenv_profile_read(AoEnv* env, double* h_ms, int32_t* h_count, void* stream)
 
 int aoenv_test_normal(int device, uint32_t seed, int n, int n_calls, double* h_out) {
     if (n < 2 || n % 2 || n_calls < 1 || !h_out) return fail("aoenv_test_normal: bad arguments");
-    AO_HIP(hipSetDevice(device));
+    DeviceGuard ao_device_guard(device);
+    if (!ao_device_guard.ok) return fail("hipSetDevice(%d) failed", device);
     uint32_t* st = nullptr; int* pos = nullptr; double* zx = nullptr;
     std::vector<uint32_t> key(kMtN);
     mt_seed(seed, key.data());

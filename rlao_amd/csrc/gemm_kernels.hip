@@ -78,9 +78,11 @@ int launch_gemm_nt(const T* X, const T* W, T* C, int M, int N, int K, int ldx, i
 // ---------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// xsplits > 1: X is itself a stack of split-K slabs X[z][M][ldx] (z < xsplits, xslab floats apart) of an earlier product; they are
+// summed in slab order while the operand is staged (chained products, e.g. v = M2C (M s), need no reduction launch in between).
 __global__ void __launch_bounds__(256) k_gemm_nt_mfma(const float* __restrict__ X, const float* __restrict__ W,
                                                       float* __restrict__ Cpart, int M, int N, int K, int ldx,
-                                                      int ldw, int kslice) {
+                                                      int ldw, int kslice, int xsplits, size_t xslab) {
     constexpr int BM = 64, BN = 64, BK = 32, LDT = BK + 1;
     __shared__ float xs[BM * LDT];
     __shared__ float ws[BN * LDT];
@@ -107,14 +109,23 @@ __global__ void __launch_bounds__(256) k_gemm_nt_mfma(const float* __restrict__ 
             wv[pass] = xv[pass];
             const int gm = m0 + r, gn = n0 + r;
             if (vec_ok && gk + 3 < kend) {
-                if (gm < M) xv[pass] = *reinterpret_cast<const float4*>(X + (size_t)gm * ldx + gk);
+                if (gm < M) {
+                    xv[pass] = *reinterpret_cast<const float4*>(X + (size_t)gm * ldx + gk);
+                    for (int z = 1; z < xsplits; ++z) {
+                        const float4 t = *reinterpret_cast<const float4*>(X + (size_t)z * xslab + (size_t)gm * ldx + gk);
+                        xv[pass].x += t.x; xv[pass].y += t.y; xv[pass].z += t.z; xv[pass].w += t.w;
+                    }
+                }
                 if (gn < N) wv[pass] = *reinterpret_cast<const float4*>(W + (size_t)gn * ldw + gk);
             } else {
                 float* xp = reinterpret_cast<float*>(&xv[pass]);
                 float* wp = reinterpret_cast<float*>(&wv[pass]);
                 for (int d = 0; d < 4; ++d) {
                     if (gk + d < kend) {
-                        if (gm < M) xp[d] = X[(size_t)gm * ldx + gk + d];
+                        if (gm < M) {
+                            xp[d] = X[(size_t)gm * ldx + gk + d];
+                            for (int z = 1; z < xsplits; ++z) xp[d] += X[(size_t)z * xslab + (size_t)gm * ldx + gk + d];
+                        }
                         if (gn < N) wp[d] = W[(size_t)gn * ldw + gk + d];
                     }
                 }
@@ -175,10 +186,10 @@ int gemm_splits(int M, int N, int K) {
 }
 
 int launch_gemm_nt_mfma(const float* X, const float* W, float* Cpart, int M, int N, int K, int ldx, int ldw, int splits,
-                        hipStream_t st) {
+                        hipStream_t st, int xsplits, size_t xslab) {
     const int kslice = cdiv(cdiv(K, splits), 32) * 32;
     dim3 grid(cdiv(N, 64), cdiv(M, 64), splits);
-    hipLaunchKernelGGL(k_gemm_nt_mfma, grid, dim3(256), 0, st, X, W, Cpart, M, N, K, ldx, ldw, kslice);
+    hipLaunchKernelGGL(k_gemm_nt_mfma, grid, dim3(256), 0, st, X, W, Cpart, M, N, K, ldx, ldw, kslice, xsplits, xslab);
     AO_HIP(hipGetLastError());
     return 0;
 }
@@ -186,7 +197,7 @@ int launch_gemm_nt_mfma(const float* X, const float* W, float* Cpart, int M, int
 // ---------------------------------------------------------------------------------------------------
 // Step epilogue, one workgroup per env   (MAIN/OOPAOEnv/OOPAOEnv.py:491, 508-518, 536):
 //   obs_img = vec_to_img(-v) * 1e6 ; reward = -||obs_img||_2
-//   dm.coefs = dm.coefs * leak + img_to_vec(action) * 1e-6          (do_integrate)
+//   dm.coefs = dm_prev * leak + img_to_vec(action) * 1e-6 ; dm_prev = dm.coefs          (do_integrate)
 // With gain_from_obs != 0 the action is the integrator command gain * obs_img of the PREVIOUS
 // observation held in `obs` (closed-loop driver MAIN/integrator_oopao_razor.py:70-71); the previous
 // image is consumed before it is overwritten.
@@ -209,13 +220,15 @@ __global__ void __launch_bounds__(1024) k_recon_finish(const FinishArgs<T> f) {
         const int px = f.act_idx[k];
         if (f.do_integrate) {
             const T a = (f.gain_from_obs != (T)0) ? f.gain_from_obs * ob[px] : f.action[(size_t)e * img + px];
-            T* c = f.coefs + (size_t)e * f.n_valid_act + k;
+            const size_t ck = (size_t)e * f.n_valid_act + k;
             // img_to_vec(action)*1e-6 (OOPAOEnv.py:491): the wrappers hand over float32 actions and NumPy keeps
             // float32 for array * python-float, so the increment is a float32 product; a float64 action that is
             // not float32-representable (env driven without the torch wrapper) keeps the float64 product.
             const float af = (float)a;
             const T inc = ((T)af == a) ? (T)(af * 1e-6f) : a * (T)1e-6;
-            *c = (*c) * f.leak + inc;
+            const T cn = f.dm_prev[ck] * f.leak + inc;           // dm.coefs = dm_prev * leak + action ; dm_prev = dm.coefs  (:508-509)
+            f.coefs[ck] = cn;
+            f.dm_prev[ck] = cn;
         }
         T acc = vv[k];
         for (int z = 1; z < f.splits; ++z) acc += vv[(size_t)z * slab + k];      // split-K slabs, fixed order

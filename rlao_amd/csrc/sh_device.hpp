@@ -285,8 +285,9 @@ __device__ inline void tail_from_slopes(const T* sl, T* img_s, double* red, cons
                 const T act = (f.gain_from_obs != (T)0) ? f.gain_from_obs * prev : prev;
                 const float af = (float)act;                      // float32 increment, see k_recon_finish
                 const T inc = ((T)af == act) ? (T)(af * 1e-6f) : act * (T)1e-6;
-                T* c = f.coefs + (size_t)e * A + k;
-                *c = (*c) * f.leak + inc;
+                const T cn = f.dm_prev[(size_t)e * A + k] * f.leak + inc;      // OOPAOEnv.py:508-509
+                f.coefs[(size_t)e * A + k] = cn;
+                f.dm_prev[(size_t)e * A + k] = cn;
             }
             const T o = -mine * (T)1e6;
             img_s[px] = o;

@@ -143,10 +143,11 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
     lds_barrier();
     if (has_act) cimg[act_px] = act_c;
     // the integrator's input of this lane's actuator (previous observation, or the caller's action): needed only in stage C
-    float act_prev = 0.f;
+    float act_prev = 0.f, dm_prev_c = 0.f;
     if (a.fa.do_integrate) {
         const size_t io = (size_t)e * (nA * nA) + (has_act ? act_px : 0);
         act_prev = (a.fa.gain_from_obs != 0.f) ? a.fa.obs[io] : a.fa.action[io];
+        dm_prev_c = a.fa.dm_prev[(size_t)e * k.n_valid_act + (has_act ? tid : 0)];     // env.dm_prev (OOPAOEnv.py:508)
     }
     float breg[2][KS];
 #pragma unroll
@@ -592,7 +593,9 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
             const float mine = part == 0 ? acc[0] : (part == 1 ? acc[1] : (part == 2 ? acc[2] : acc[3]));
             if (a.fa.do_integrate) {
                 const float act = (a.fa.gain_from_obs != 0.f) ? a.fa.gain_from_obs * act_prev : act_prev;
-                a.fa.coefs[(size_t)e * A + tid] = act_c * a.fa.leak + act * 1e-6f;      // float32 increment (k_recon_finish)
+                const float cn = dm_prev_c * a.fa.leak + act * 1e-6f;                    // float32 increment (k_recon_finish)
+                a.fa.coefs[(size_t)e * A + tid] = cn;
+                a.fa.dm_prev[(size_t)e * A + tid] = cn;
             }
             const float o = -mine * 1e6f;
             img_s[act_px] = o;

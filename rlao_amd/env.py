@@ -22,6 +22,13 @@ from . import _lib as L
 from . import calib
 
 _NP_DT = {"f32": np.float32, "f64": np.float64}
+# wfs.cam settings per env flavour: (before the calibration, after it) -- MAIN/OOPAOEnv/OOPAOEnv.py:379; OOPAOEnvRazor.py:243-250, 332-333
+CAMERAS = {
+    "ideal": ({}, {}),
+    "papyrus": ({}, dict(photonNoise=True)),
+    "razor": (dict(sensor="CMOS", FWC=10000, bits=10, QE=0.56, darkCurrent=5, integrationTime="samplingTime"),
+              dict(photonNoise=True, readoutNoise=14)),
+}
 
 
 def _torch():
@@ -288,9 +295,11 @@ class _TelProxy:
         raise AttributeError("the telescope can be multiplied only with the DM and the WFS of this env")
 
     def resetOPD(self):
-        """Flat wave-front for a telescope that is not paired to the atmosphere (OOPAO/Telescope.py:566-579);
-        the batched env is always paired and re-derives its OPD from the screens on the next step."""
-        return None
+        """Flat wave-front (OOPAO/Telescope.py:566-579): ``env.tel.resetOPD(); env.tel.computePSF(4)`` gives the diffraction-limited
+        PSF (MAIN/integrator_network.py:61-64).  The env stays paired to its atmosphere: the next measurement / step re-derives the
+        residual phase from the screens and the DM."""
+        e = self._e
+        e._shard.upload_state(L.B_PHASE, np.zeros((e.n_envs, e.R * e.R)), e._stream())
 
     @property
     def OPD(self):
@@ -378,11 +387,19 @@ class BatchedAOEnv:
         """Kept for call compatibility (MAIN/PO4AO/mbrl.py:27); the parameters come from ``set_params``."""
         self.param_file, self.oopao_path = param_file, oopao_path
 
-    def set_params(self, args=None, wfs_type="pyramid", modal_basis="zernike", gainCL=0.5, m2c=None, second_dm=None, **kw):
+    def set_params(self, args=None, wfs_type="pyramid", modal_basis="zernike", gainCL=0.5, m2c=None, second_dm=None,
+                   camera="papyrus", **kw):
         """Builds the loop (MAIN/OOPAOEnv/OOPAOEnv.py:93-385).  ``wfs_type`` is "pyramid" (the reference's default,
         Papyrus) or "shackhartmann" (OOPAOEnvRazor.py:232-238).  ``second_dm=dict(nSubaperture=n)`` chains a second DM of
         that pitch behind the first (``tel*dm1*dm2*wfs``, BASELINE configs[4]): commands, observations and actions then
-        cover both mirrors (``calib.CompositeDM``: one block-diagonal actuator image, separable like a single mirror)."""
+        cover both mirrors (``calib.CompositeDM``: one block-diagonal actuator image, separable like a single mirror).
+        ``camera``: the WFS detector the env ends set_params with -- "papyrus" (default): ``wfs.cam.photonNoise = True``
+        (OOPAOEnv.py:379); "razor": the Razor env's CMOS camera (QE 0.56, FWC 1e4, 10-bit ADC, dark current 5 e-/s set before the
+        calibration, photon noise and 14 e- read-out noise after it, OOPAOEnvRazor.py:243-250, 332-333); "ideal": no noise (the
+        parity configuration: the reference's noisy frames are wall-clock seeded, Detector.py:127-130)."""
+        if camera not in CAMERAS:
+            raise ValueError(f"camera must be one of {sorted(CAMERAS)}")
+        self.camera = camera
         if wfs_type in ("shackhartmann", "sh"):
             self.wfs_type = "sh"
         elif wfs_type in ("pyramid", "pyr"):
@@ -450,12 +467,19 @@ class BatchedAOEnv:
         self.SR = []
         self.atm, self.dm, self.tel, self.wfs = _AtmProxy(self), _DmProxy(self), _TelProxy(self), _WfsProxy(self)
         self.wfs.tag = "shackHartmann" if self.wfs_type == "sh" else "pyramid"
+        pre, post = CAMERAS[camera]
+        for k, v in pre.items():
+            object.__setattr__(self.wfs.cam, k, p.samplingTime if v == "samplingTime" else v)
+        self._push_detector()
         # flat measurement, then the initial screens (MAIN/OOPAOEnv/OOPAOEnv.py:312-322)
         self.measure()
         self.generate_new_phase_screen(10)
+        for k, v in post.items():                                   # OOPAOEnv.py:379 / OOPAOEnvRazor.py:332-333
+            object.__setattr__(self.wfs.cam, k, v)
+        self._push_detector()
         return self
 
-    def _make_shard(self, n_env, dtype, n_layer, max_group) -> Shard:
+    def _make_shard(self, n_env, dtype, n_layer, max_group, cam_pre=False) -> Shard:
         p, at, dmt = self.param, self._atm_tables, self._dm_tables
         valid_idx = self._wfs_valid_idx
         cfg = dict(dtype=L.F32 if dtype == "f32" else L.F64, n_env=n_env, resolution=self.R, n_layer=n_layer,
@@ -471,6 +495,17 @@ class BatchedAOEnv:
             cfg.update(wfs_type=L.WFS_PYRAMID, pyr_n_res=pt.nRes, pyr_n_theta=self._wfs_n_theta,
                        pyr_centering=int(pt.psf_centering), pyr_norm_valid=pt.norm_valid, pyr_q_lo=pt.q_lo, pyr_q_hi=pt.q_hi)
         sh = Shard(cfg, self.device_index)
+        pre = CAMERAS[getattr(self, "camera", "ideal")][0]
+        if pre and cam_pre:
+            # the interaction-matrix pokes see the camera as it is set at that point of set_params (the WFS constructor measured its
+            # reference slopes and units before, with the default camera): InteractionMatrix(noise='off') clears photon / read-out
+            # noise only (OOPAO/calibration/InteractionMatrix.py:37-40); QE, full well, ADC and the dark shot noise stay.  Every
+            # calibration shard draws its dark noise from its own stream.
+            self._cal_count = getattr(self, "_cal_count", 0) + 1
+            d = L.AoDetector(photon_noise=0, bits=int(pre.get("bits") or 0), emccd=int(pre.get("sensor") == "EMCCD"), env_index_offset=0,
+                             qe=float(pre.get("QE", 1)), dark_electrons=float(pre.get("darkCurrent", 0)) * float(self.param.samplingTime),
+                             fwc=float(pre.get("FWC") or 0), gain=1.0, readout_noise=0.0, seed=0xCA11B000 + self._cal_count)
+            L.check(sh.lib.aoenv_set_detector(sh.h, C.byref(d), None))
         sh.upload(L.C_PUPIL, self.pupil.astype(np.uint8))
         if self._dm_separable:
             sh.upload(L.C_DM_GX, dmt.gx)
@@ -558,9 +593,15 @@ class BatchedAOEnv:
         # pokes per calibration shard: whole measurement groups, bounded so that the Pyramid's nRes^2 scratch fits
         batch = A_ if self.wfs_type == "sh" else max(n_meas, (96 // n_meas) * n_meas)
         sig = np.zeros((A_, self.nSignal))
-        for a0 in range(0, A_, batch):
-            n = min(batch, A_ - a0)
-            cal = self._make_shard(n, "f64", n_layer=0, max_group=n_meas)
+        # every DM is poked by its own InteractionMatrix call (an un-paired telescope keeps only the last DM's OPD,
+        # OOPAO/DeformableMirror.py:474-476): the measurement groups do not straddle two mirrors
+        dms = [self._dm_tables.dm1.nValidAct, self._dm_tables.dm2.nValidAct] if hasattr(self._dm_tables, "dm2") else [A_]
+        spans, lo = [], 0
+        for n_dm in dms:
+            spans += [(a0, min(batch, lo + n_dm - a0)) for a0 in range(lo, lo + n_dm, batch)]
+            lo += n_dm
+        for a0, n in spans:
+            cal = self._make_shard(n, "f64", n_layer=0, max_group=n_meas, cam_pre=True)
             try:
                 cal.upload(L.C_SH_REF, ref)
                 cal.upload(L.C_WFS_UNITS, np.array([units]))
@@ -591,7 +632,7 @@ class BatchedAOEnv:
                          env_index_offset=int(self.env_index_offset), qe=float(cam.QE),
                          dark_electrons=float(cam.darkCurrent) * float(t_int), fwc=float(cam.FWC or 0), gain=float(cam.gain),
                          readout_noise=float(cam.readoutNoise), seed=int(self.detector_seed) & 0xFFFFFFFFFFFFFFFF)
-        L.check(self._shard.lib.aoenv_set_detector(self._shard.h, C.byref(d)))
+        L.check(self._shard.lib.aoenv_set_detector(self._shard.h, C.byref(d), C.c_void_p(self._stream())))
 
     def _push_wind(self, reset: bool):
         p = self.param
@@ -700,6 +741,7 @@ class BatchedAOEnv:
             "buff": sh.get_buff(p.nLayer).copy(),
             "mt": sh.download(L.B_MT_STATE, (p.nLayer, self.n_envs, 625), st, dtype=np.uint32),
             "coefs": sh.download(L.B_COEFS, (self.n_envs, self.nValidAct), st),
+            "dm_prev": sh.download(L.B_DM_PREV, (self.n_envs, self.nValidAct), st),
             "signal": sh.download(L.B_SIGNAL, (self.n_envs, self.nSignal), st),
             "counters": sh.download(L.B_COUNTERS, (4,), st, dtype=np.uint32),
             "obs": self._obs.detach().cpu().numpy().copy(),
@@ -715,6 +757,7 @@ class BatchedAOEnv:
         sh.set_buff(state["buff"])
         sh.upload_state(L.B_MT_STATE, state["mt"], st, dtype=np.uint32)
         sh.upload_state(L.B_COEFS, state["coefs"], st)
+        sh.upload_state(L.B_DM_PREV, state.get("dm_prev", state["coefs"]), st)
         sh.upload_state(L.B_SIGNAL, state["signal"], st)
         sh.upload_state(L.B_COUNTERS, state["counters"], st, dtype=np.uint32)
         self._obs.copy_(_torch().as_tensor(state["obs"], device=self.device, dtype=self.tdtype))

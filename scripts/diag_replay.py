@@ -14,7 +14,7 @@ env = BatchedAOEnv(n_envs=len(seeds), device=0, dtype=dtype)
 pyr = "cfg_wfs" in g
 if pyr:
     prm.update(modulation=float(g["cfg_modulation"]), psfCentering=bool(g["cfg_centering"]))
-env.set_params(prm, wfs_type="pyramid" if pyr else "shackhartmann", m2c=g["m2c"])
+env.set_params(prm, camera="ideal", wfs_type="pyramid" if pyr else "shackhartmann", m2c=g["m2c"])
 print("units", env.slopes_units, float(g["slopes_units"]) if "slopes_units" in g else 1.0, "imat relerr", np.abs(env.imat - g["imat"]).max() / np.abs(g["imat"]).max(),
       "recon relerr", np.abs(env.reconstructor - g["recon"]).max() / np.abs(g["recon"]).max())
 env.env_seed_stride = (seeds[1] - seeds[0]) if len(seeds) > 1 else 1

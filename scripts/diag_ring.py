@@ -6,7 +6,7 @@ from rlao_amd import _lib as L
 g = np.load("tests/golden/tiny_sh.npz")
 prm = dict(diameter=1.6, nSubaperture=4, nPixelPerSubap=6, nModes=8, nLoop=64)
 env = BatchedAOEnv(n_envs=1, device=0, dtype="f64")
-env.set_params(prm, wfs_type="shackhartmann", m2c=g["m2c"])
+env.set_params(prm, camera="ideal", wfs_type="shackhartmann", m2c=g["m2c"])
 env.generate_new_phase_screen(17)
 at = env._atm_tables
 zx = env._shard.download(L.B_XI, (1, at.n_inner + at.n_outer))[0]

@@ -39,41 +39,50 @@ def test_every_declared_symbol_is_exported_and_bound(built_lib):
     assert lib.aoenv_abi_version() == built_lib.ABI_VERSION
 
 
+def _header_enumerators():
+    """Every AOENV_* enumerator of the header's enum blocks (not the #defines)."""
+    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    names = []
+    for body in re.findall(r"enum\s*\w*\s*\{(.*?)\}", src, flags=re.S):
+        names += re.findall(r"\b(AOENV_[A-Z0-9_]+)\b", body)
+    return sorted(set(names))
+
+
 def test_cfg_layout_and_enums_match_header(built_lib, tmp_path):
-    fields = [f[0] for f in built_lib.AoCfg._fields_]
-    prog = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void){",
-            'printf("size %zu\\n", sizeof(AoCfg));']
-    prog += [f'printf("{f} %zu\\n", offsetof(AoCfg, {f}));' for f in fields]
-    enums = ["AOENV_F32", "AOENV_F64", "AOENV_WFS_SH", "AOENV_C_PUPIL", "AOENV_C_AB", "AOENV_C_INNER_IDX",
-             "AOENV_C_OUTER_IDX", "AOENV_C_LAYER_WEIGHT", "AOENV_C_DM_GX", "AOENV_C_DM_GY", "AOENV_C_DM_MODES",
-             "AOENV_C_ACT_IDX", "AOENV_C_WFS_AMP", "AOENV_C_SH_SUBAP_IDX", "AOENV_C_SH_REF", "AOENV_C_WFS_UNITS",
-             "AOENV_C_RECON", "AOENV_C_PYR_MASK", "AOENV_C_PYR_TT", "AOENV_C_RECON_FACTORS", "AOENV_WFS_PYRAMID", "AOENV_B_SCREEN", "AOENV_B_OPD_ATM", "AOENV_B_COEFS", "AOENV_B_PHASE", "AOENV_B_FRAME",
-             "AOENV_B_SIGNAL", "AOENV_B_TOTAL", "AOENV_B_RESIDUAL", "AOENV_B_WFS_MAX", "AOENV_B_XI", "AOENV_K_COUNT",
-             "AOENV_OPT_FAST_WFS", "AOENV_OPT_MFMA_GEMM", "AOENV_OPT_FAST_TRIG", "AOENV_OPT_STORE_ATM_OPD", "AOENV_OPT_FUSED_TAIL"]
+    L = built_lib
+    structs = {"AoCfg": L.AoCfg, "AoDetector": L.AoDetector}
+    enums = _header_enumerators()
+    prog = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void){"]
+    for sname, st in structs.items():
+        prog.append(f'printf("{sname}.size %zu\\n", sizeof({sname}));')
+        prog += [f'printf("{sname}.{f[0]} %zu\\n", offsetof({sname}, {f[0]}));' for f in st._fields_]
     prog += [f'printf("{e} %d\\n", (int){e});' for e in enums]
-    prog += ["return 0;}"]
+    prog += ['printf("AOENV_ABI_VERSION %d\\n", (int)AOENV_ABI_VERSION);', "return 0;}"]
     src = tmp_path / "layout.c"
     src.write_text("\n".join(prog))
     exe = tmp_path / "layout"
     subprocess.run(["gcc", "-std=c99", "-o", str(exe), str(src)], check=True)
     out = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
-    L = built_lib
-    assert int(out["size"]) == C.sizeof(L.AoCfg)
-    for f in fields:
-        assert int(out[f]) == getattr(L.AoCfg, f).offset, f
-    mirror = dict(AOENV_F32=L.F32, AOENV_F64=L.F64, AOENV_WFS_SH=L.WFS_SH, AOENV_C_PUPIL=L.C_PUPIL, AOENV_C_AB=L.C_AB,
-                  AOENV_C_INNER_IDX=L.C_INNER_IDX, AOENV_C_OUTER_IDX=L.C_OUTER_IDX, AOENV_C_LAYER_WEIGHT=L.C_LAYER_WEIGHT,
-                  AOENV_C_DM_GX=L.C_DM_GX, AOENV_C_DM_GY=L.C_DM_GY, AOENV_C_DM_MODES=L.C_DM_MODES, AOENV_C_ACT_IDX=L.C_ACT_IDX,
-                  AOENV_C_WFS_AMP=L.C_WFS_AMP, AOENV_C_SH_SUBAP_IDX=L.C_SH_SUBAP_IDX, AOENV_C_SH_REF=L.C_SH_REF,
-                  AOENV_C_WFS_UNITS=L.C_WFS_UNITS, AOENV_C_RECON=L.C_RECON, AOENV_C_PYR_MASK=L.C_PYR_MASK, AOENV_C_PYR_TT=L.C_PYR_TT,
-                  AOENV_C_RECON_FACTORS=L.C_RECON_FACTORS, AOENV_WFS_PYRAMID=L.WFS_PYRAMID, AOENV_B_SCREEN=L.B_SCREEN,
-                  AOENV_B_OPD_ATM=L.B_OPD_ATM, AOENV_B_COEFS=L.B_COEFS, AOENV_B_PHASE=L.B_PHASE, AOENV_B_FRAME=L.B_FRAME,
-                  AOENV_B_SIGNAL=L.B_SIGNAL, AOENV_B_TOTAL=L.B_TOTAL, AOENV_B_RESIDUAL=L.B_RESIDUAL,
-                  AOENV_B_WFS_MAX=L.B_WFS_MAX, AOENV_B_XI=L.B_XI, AOENV_K_COUNT=len(L.KERNEL_NAMES),
-                  AOENV_OPT_FAST_WFS=L.OPT_FAST_WFS, AOENV_OPT_MFMA_GEMM=L.OPT_MFMA_GEMM, AOENV_OPT_FAST_TRIG=L.OPT_FAST_TRIG,
-                  AOENV_OPT_STORE_ATM_OPD=L.OPT_STORE_ATM_OPD, AOENV_OPT_FUSED_TAIL=L.OPT_FUSED_TAIL)
-    for k, v in mirror.items():
-        assert int(out[k]) == v, k
+    for sname, st in structs.items():
+        assert int(out[f"{sname}.size"]) == C.sizeof(st), sname
+        for f in st._fields_:
+            assert int(out[f"{sname}.{f[0]}"]) == getattr(st, f[0]).offset, (sname, f[0])
+    assert int(out["AOENV_ABI_VERSION"]) == L.ABI_VERSION
+    # the Python mirror of every enumerator: AOENV_C_X -> _lib.C_X, AOENV_B_X -> B_X, AOENV_OPT_X -> OPT_X, AOENV_F32/F64/WFS_*
+    checked = 0
+    for e in enums:
+        short = e[len("AOENV_"):]
+        if short.startswith("K_"):
+            continue                                            # AoKernel: mirrored by the order of KERNEL_NAMES
+        if short.endswith("_COUNT"):
+            continue
+        assert hasattr(L, short), f"{e} has no mirror {short} in rlao_amd/_lib.py"
+        assert int(out[e]) == getattr(L, short), e
+        checked += 1
+    assert checked >= 40
+    assert int(out["AOENV_K_COUNT"]) == len(L.KERNEL_NAMES)
+    assert int(out["AOENV_B_COUNT"]) == 1 + max(getattr(L, n) for n in dir(L) if n.startswith("B_"))
+    assert int(out["AOENV_C_COUNT"]) == 1 + max(getattr(L, n) for n in dir(L) if n.startswith("C_") and isinstance(getattr(L, n), int))
 
 
 def test_no_gpu_means_loud_failure(built_lib):

@@ -37,9 +37,10 @@ def test_switches_agree_small():
     for opts in [dict(), {L.OPT_DEFER_RING: 0}, {L.OPT_FUSED_STEP: 0}, {L.OPT_FUSED_STEP: 0, L.OPT_COEFS_IMAGE: 1},
                  {L.OPT_FUSED_STEP: 0, L.OPT_COEFS_IMAGE: 1, L.OPT_MFMA_GEMM: 0}, {L.OPT_FUSED_STEP: 0, L.OPT_FAST_TRIG: 0}, {L.OPT_FAST_WFS: 0}, {L.OPT_MFMA_GEMM: 0}, {L.OPT_FAST_TRIG: 0}, {L.OPT_FUSED_TAIL: 0},
                  {L.OPT_FUSED_TAIL: 0, L.OPT_MFMA_GEMM: 0},
+                 {L.OPT_FUSED_TAIL: 0, L.OPT_FACTORED_RECON: 0}, {L.OPT_FUSED_TAIL: 0, L.OPT_FACTORED_RECON: 0, L.OPT_MFMA_GEMM: 0},
                  {L.OPT_FAST_WFS: 0, L.OPT_MFMA_GEMM: 0, L.OPT_FAST_TRIG: 0, L.OPT_FUSED_TAIL: 0}]:
         env = BatchedAOEnv(n_envs=3, device=0, dtype="f32")
-        env.set_params(SMALL, wfs_type="shackhartmann")
+        env.set_params(SMALL, camera="ideal", wfs_type="shackhartmann")
         for k, v in opts.items():
             L.check(env._shard.lib.aoenv_set_option(env._shard.h, k, v))
         out = _run(env, 12, 5)
@@ -64,7 +65,7 @@ def test_large_dm_row_products_agree():
     outs = {}
     for name, dtype, opt in (("rows", "f32", 1), ("tiles", "f32", 0), ("f64", "f64", 0)):
         env = BatchedAOEnv(n_envs=2, device=0, dtype=dtype)
-        env.set_params(geo, wfs_type="shackhartmann")
+        env.set_params(geo, camera="ideal", wfs_type="shackhartmann")
         assert env.nActuator == 37 and env.R == 216
         L.check(env._shard.lib.aoenv_set_option(env._shard.h, L.OPT_COEFS_IMAGE, opt))
         outs[name] = _run(env, 6, 11)
@@ -85,7 +86,7 @@ def test_full_size_batch_invariance_and_determinism():
     import torch
     from rlao_amd.env import BatchedAOEnv
     env = BatchedAOEnv(n_envs=256, device=0, dtype="f32", env_seed_stride=0)     # every env: seed 17
-    env.set_params(C2, wfs_type="shackhartmann")
+    env.set_params(C2, camera="ideal", wfs_type="shackhartmann")
     a = _run(env, 8, 17)
     b = _run(env, 8, 17)
     for (o, f, r, s), (o2, f2, r2, s2) in zip(a, b):
@@ -105,7 +106,7 @@ def test_run_integrator_equals_stepping():
     import torch
     from rlao_amd.env import BatchedAOEnv
     env = BatchedAOEnv(n_envs=4, device=0, dtype="f32")
-    env.set_params(SMALL, wfs_type="shackhartmann", gainCL=0.4)
+    env.set_params(SMALL, camera="ideal", wfs_type="shackhartmann", gainCL=0.4)
     a = _run(env, 10, 3, gain=0.4)
     env.generate_new_phase_screen(3)
     env.dm.coefs = 0
@@ -140,7 +141,7 @@ def test_random_actions_match_oracle_c2():
     from oracle import ao_oracle as O
     from rlao_amd.env import BatchedAOEnv
     env = BatchedAOEnv(n_envs=3, device=0, dtype="f32", env_seed_stride=100)
-    env.set_params(C2, wfs_type="shackhartmann")
+    env.set_params(C2, camera="ideal", wfs_type="shackhartmann")
     env.generate_new_phase_screen(23)
     env.dm.coefs = 0
     env.measure()
@@ -175,7 +176,7 @@ def test_single_env_flavour_returns_reference_types(golden_dir):
     g = np.load(os.path.join(golden_dir, "small_sh.npz"))
     env = OOPAO(device=0, dtype="f64")
     env.set_params_file("Conf.parameterFile_oopao_parser", "AO_OOPAO")
-    env.set_params(SMALL, wfs_type="shackhartmann", m2c=g["m2c"])
+    env.set_params(SMALL, camera="ideal", wfs_type="shackhartmann", m2c=g["m2c"])
     env.atm.generateNewPhaseScreen(17)
     env.dm.coefs = 0
     env.tel * env.dm * env.wfs
@@ -216,7 +217,7 @@ def test_c_abi_reports_errors():
     from rlao_amd.env import BatchedAOEnv
     lib = L.load()
     env = BatchedAOEnv(n_envs=2, device=0, dtype="f32")
-    env.set_params(SMALL, wfs_type="shackhartmann")
+    env.set_params(SMALL, camera="ideal", wfs_type="shackhartmann")
     h = env._shard.h
     assert lib.aoenv_step(h, 10 ** 6, C.c_void_p(env._obs.data_ptr()), C.c_void_p(env._obs.data_ptr()), None, None, None, None) != 0
     assert b"frame index" in lib.aoenv_last_error()
@@ -247,7 +248,7 @@ def test_device_phase_screens_match_oracle(dtype, n_layer):
     geo = dict(SMALL, windSpeed=[10.0, 7.0, 12.0][:n_layer], windDirection=[72.0, 0.0, 144.0][:n_layer],
                fractionalR0=[[1.0], None, [0.6, 0.25, 0.15]][n_layer - 1], altitude=[0.0] * n_layer)
     env = BatchedAOEnv(n_envs=5, device=0, dtype=dtype)
-    env.set_params(geo, wfs_type="shackhartmann")
+    env.set_params(geo, camera="ideal", wfs_type="shackhartmann")
     env.env_seed_stride = 7
     env.generate_new_phase_screen(41)
     at = env._atm_tables
@@ -283,7 +284,7 @@ def test_pyramid_prime_radix_fft_matches_oracle(n_sub):
                fractionalR0=[1.0], altitude=[0.0], nModes=4, nLoop=16)
     for centering, mod in ((True, 0.0), (False, 2.0)):
         env = BatchedAOEnv(n_envs=2, device=0, dtype="f64")
-        env.set_params(dict(geo, psfCentering=centering, modulation=mod), wfs_type="pyramid")
+        env.set_params(dict(geo, psfCentering=centering, modulation=mod), camera="ideal", wfs_type="pyramid")
         ref = O.OracleEnv(resolution=6 * n_sub, diameter=D, n_subap=n_sub, r0=0.13, L0=30.0, windSpeed=[10.0],
                           windDirection=[72.0], fractionalR0=[1.0], altitude=[0.0], m2c=env.M2C_CL, n_modes=4,
                           wfs_type="pyramid", modulation=mod, psf_centering=centering)
@@ -308,7 +309,7 @@ def test_checkpoint_resume_is_bitwise(noise):
 
     def make():
         env = BatchedAOEnv(n_envs=3, device=0, dtype="f32")
-        env.set_params(dict(SMALL, windSpeed=[35.0]), wfs_type="shackhartmann")       # a crossing every ~1.1 steps
+        env.set_params(dict(SMALL, windSpeed=[35.0]), camera="ideal", wfs_type="shackhartmann")       # a crossing every ~1.1 steps
         if noise:
             env.wfs.cam.photonNoise, env.wfs.cam.readoutNoise = True, 3
         return env
@@ -347,7 +348,7 @@ def test_science_psf_matches_oracle(dtype, tol):
     from rlao_amd import _lib as L
     from rlao_amd.env import BatchedAOEnv
     env = BatchedAOEnv(n_envs=3, device=0, dtype=dtype)
-    env.set_params(SMALL, wfs_type="shackhartmann")
+    env.set_params(SMALL, camera="ideal", wfs_type="shackhartmann")
     out = _run(env, 4, 9)
     phase = env._shard.download(L.B_PHASE, (3, env.R, env.R)).astype(np.float64)
     flux = env._sh_tables.flux_map
@@ -367,7 +368,7 @@ def test_history_env_on_the_device():
     from rlao_amd.env import BatchedAOEnv
     from rlao_amd.wrappers import HistoryEnv
     env = BatchedAOEnv(n_envs=4, device=0, dtype="f32")
-    env.set_params(SMALL, wfs_type="shackhartmann")
+    env.set_params(SMALL, camera="ideal", wfs_type="shackhartmann")
     h = HistoryEnv(env, n_history=5, delay=1)
     hist, info = h.reset(seed=3)
     assert hist.is_cuda and tuple(hist.shape) == (4, 5, env.nActuator, env.nActuator)
@@ -404,7 +405,7 @@ def test_two_dms_match_reference_and_oracle(golden_dir):
     g = np.load(os.path.join(golden_dir, "two_dm.npz"))
     ns2 = int(g["cfg_ns2"])
     env = BatchedAOEnv(n_envs=3, device=0, dtype="f64")
-    env.set_params(SMALL, wfs_type="shackhartmann", second_dm=dict(nSubaperture=ns2))
+    env.set_params(SMALL, camera="ideal", wfs_type="shackhartmann", second_dm=dict(nSubaperture=ns2))
     A1, A2 = g["coefs1"].shape[1], g["coefs2"].shape[1]
     assert env.nValidAct == A1 + A2 and env.nActuator == 9 + ns2 + 1
     env._shard.set_atm_opd(g["opd_atm"].reshape(3, -1))
@@ -417,7 +418,7 @@ def test_two_dms_match_reference_and_oracle(golden_dir):
     env.close()
     for dtype, tol in (("f64", 1e-6), ("f32", 5e-5)):
         env = BatchedAOEnv(n_envs=2, device=0, dtype=dtype)
-        env.set_params(SMALL, wfs_type="shackhartmann", second_dm=dict(nSubaperture=ns2))
+        env.set_params(SMALL, camera="ideal", wfs_type="shackhartmann", second_dm=dict(nSubaperture=ns2))
         ref = O.OracleEnv(resolution=48, diameter=3.2, n_subap=8, r0=0.13, L0=30.0, windSpeed=[10.0], windDirection=[72.0],
                           fractionalR0=[1.0], altitude=[0.0], m2c=env.M2C_CL, n_modes=20, second_dm_nsub=ns2)
         env.generate_new_phase_screen(13)
@@ -443,7 +444,7 @@ def test_long_closed_loop_tracks_the_oracle():
     from oracle import ao_oracle as O                       # checker only
     from rlao_amd.env import BatchedAOEnv
     env = BatchedAOEnv(n_envs=2, device=0, dtype="f32")
-    env.set_params(dict(SMALL, nLoop=400), wfs_type="shackhartmann")
+    env.set_params(dict(SMALL, nLoop=400), camera="ideal", wfs_type="shackhartmann")
     ref = O.OracleEnv(resolution=48, diameter=3.2, n_subap=8, r0=0.13, L0=30.0, windSpeed=[10.0], windDirection=[72.0],
                       fractionalR0=[1.0], altitude=[0.0], m2c=env.M2C_CL, n_modes=20, nLoop=400)
     env.generate_new_phase_screen(29)

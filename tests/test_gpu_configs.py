@@ -1,0 +1,181 @@
+"""GPU: the BASELINE.json configurations other than the headline one, at their full per-GPU size, through the C ABI.
+
+configs[2] 8 m / 40x40 Pyramid, 1024 envs          -> golden replay c3_pyr (tests/test_gpu_parity.py) + the batch tests here
+configs[3] 39 m / 80x80 Shack-Hartmann, 512 envs per GPU -> reference measurement c4_sh.npz, ring extrusion vs the oracle's operator,
+                                                            batch invariance
+configs[4] 3 layers + 2 chained DMs, 256 envs per GPU    -> golden replay c5_mcao (tests/test_gpu_parity.py) + distinct seeds vs the oracle
+
+The checker is the NumPy oracle (pinned to the reference by tests/test_oracle_golden.py at these very sizes) and the reference's
+own recordings in tests/golden/; /root/reference is never read here.
+"""
+import copy
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+C3 = dict(diameter=8.0, nSubaperture=40, nPixelPerSubap=6, r0=0.13, L0=30.0, windSpeed=[10.0], windDirection=[72.0],
+          fractionalR0=[1.0], altitude=[0.0], nModes=50, modulation=0.0, nLoop=32)
+C4 = dict(diameter=39.0, nSubaperture=80, nPixelPerSubap=6, r0=0.13, L0=30.0, windSpeed=[10.0], windDirection=[72.0],
+          fractionalR0=[1.0], altitude=[0.0], nModes=300, nLoop=32)
+C5 = dict(diameter=8.0, nSubaperture=20, nPixelPerSubap=6, r0=0.13, L0=30.0, windSpeed=[10.0, 12.0, 11.0],
+          windDirection=[0.0, 72.0, 144.0], fractionalR0=[0.45 / 0.65, 0.1 / 0.65, 0.1 / 0.65], altitude=[0.0, 1000.0, 5000.0],
+          nModes=50, nLoop=32)
+
+
+def _episode(env, steps, seed, gain=0.5):
+    import torch
+    env.generate_new_phase_screen(seed)
+    env.dm.coefs = 0
+    env.measure()
+    obs = env.reset_soft()
+    out = []
+    for i in range(steps):
+        obs, frame, rew, sr, done, info = env.step(i, gain * obs)
+        out.append((obs.clone(), frame.clone(), rew.clone(), sr.clone()))
+    torch.cuda.synchronize()
+    return out
+
+
+def _assert_batch_invariant(env, steps, seed=17):
+    """Same seed in every env -> bitwise identical envs and bitwise identical reruns; stride 1 -> env 0 unchanged, others differ."""
+    import torch
+    env.env_seed_stride = 0
+    a = _episode(env, steps, seed)
+    b = _episode(env, steps, seed)
+    for x, y in zip(a, b):
+        assert all(torch.equal(p, q) for p, q in zip(x, y))
+    o, f, r, s = a[-1]
+    assert torch.isfinite(o).all() and torch.isfinite(f).all() and torch.isfinite(r).all() and torch.isfinite(s).all()
+    assert torch.equal(o, o[:1].expand_as(o)) and torch.equal(f, f[:1].expand_as(f))
+    assert torch.equal(r, r[:1].expand_as(r)) and torch.equal(s, s[:1].expand_as(s))
+    env.env_seed_stride = 1
+    c = _episode(env, steps, seed)
+    assert torch.equal(c[-1][0][0], o[0])                       # env 0 still has the same seed
+    assert not torch.equal(c[-1][0][-1], o[-1])                 # the last env does not
+    assert float(c[-1][2].std()) > 0
+    return a
+
+
+def test_c3_pyramid_1024_envs_batch_invariance_and_determinism():
+    """BASELINE configs[2]: 1024 envs of the 8 m / 40x40 Pyramid geometry (R = 240, FFT length 528 = 16 * 3 * 11)."""
+    from rlao_amd.env import BatchedAOEnv
+    env = BatchedAOEnv(n_envs=1024, device=0, dtype="f32", env_seed_stride=0)
+    try:
+        env.set_params(C3, camera="ideal", wfs_type="pyramid")
+        assert env.R == 240 and env._pyr_tables.nRes == 528 and env.nValidAct == 1353 and env.nSignal == 2608
+        _assert_batch_invariant(env, 4)
+    finally:
+        env.close()
+
+
+def test_c5_mcao_256_envs_distinct_seeds_match_oracle():
+    """BASELINE configs[4] per-GPU shard: 256 envs, 3 layers, two chained DMs (21x21 + 11x11 actuators through the fused step
+    kernel), every env its own seed; envs 0, 100 and 255 against the oracle (float64 NumPy, two DMs as a stacked command)."""
+    import torch
+    from oracle import ao_oracle as O                       # checker only
+    from rlao_amd.env import BatchedAOEnv
+    env = BatchedAOEnv(n_envs=256, device=0, dtype="f32")
+    try:
+        env.set_params(C5, camera="ideal", wfs_type="shackhartmann", second_dm=dict(nSubaperture=10))
+        assert env.nValidAct == 357 + 101 and env.nActuator == 32 and env.param.nLayer == 3
+        env.generate_new_phase_screen(40)
+        env.dm.coefs = 0
+        env.measure()
+        obs = env.reset_soft()
+        base = O.OracleEnv(resolution=120, diameter=8.0, n_subap=20, r0=0.13, L0=30.0, windSpeed=C5["windSpeed"],
+                           windDirection=C5["windDirection"], fractionalR0=C5["fractionalR0"], altitude=C5["altitude"],
+                           m2c=env.M2C_CL, n_modes=50, second_dm_nsub=10)
+        picks = [0, 100, 255]
+        orcs = []
+        for k in picks:
+            o = copy.deepcopy(base)
+            o.new_episode(40 + k)
+            np.testing.assert_allclose(obs[k].cpu().numpy(), o.reset_soft(), atol=3e-5)
+            orcs.append(o)
+        for i in range(8):                                        # several ring extrusions of every layer
+            act = (0.5 * obs).float()
+            obs, frame, rew, sr, _, _ = env.step(i, act)
+            for k, o in zip(picks, orcs):
+                oo, of, orw, osr, _, _ = o.step(i, act[k].cpu().numpy())
+                np.testing.assert_allclose(obs[k].cpu().numpy(), oo, atol=3e-5, err_msg=f"env {k} step {i}")
+                np.testing.assert_allclose(float(sr[k]), osr, atol=1e-5)
+                np.testing.assert_allclose(float(rew[k]), orw, rtol=1e-4)
+                np.testing.assert_allclose(frame[k].cpu().numpy(), of, atol=5e-5 * of.max())
+        assert float(sr.std()) > 0
+        res = env.residual[:8]
+        for k, o in zip(picks, orcs):
+            np.testing.assert_allclose(res[:, k], o.residual[:8], atol=3e-3)
+    finally:
+        env.close()
+
+
+def test_c4_elt_measurement_matches_reference_and_ring_matches_oracle(golden_dir):
+    """BASELINE configs[3] geometry: 39 m, 80x80 lenslets, R = 480, 5209 actuators.
+    (a) valid lenslets / actuators, reference slopes, slope units and ONE tel*dm*wfs of a fixed wave-front + DM command against the
+        reference's own ShackHartmann / DeformableMirror (tests/golden/c4_sh.npz), float64 and float32 shards;
+    (b) the ring extrusion X = A Z + B xi of the 484^2 layer (n_outer 1940, n_inner 3856) against the oracle's operator applied to the
+        downloaded [Z | xi];
+    (c) 512 envs (the per-GPU shard of 4096 envs over 8 GPUs): batch invariance and bitwise reruns over steps that cross a pixel."""
+    import torch
+    from oracle import ao_oracle as O                       # checker only
+    from oracle.make_goldens import c4_test_opd
+    from rlao_amd import _lib as L
+    from rlao_amd.env import BatchedAOEnv
+    g = np.load(os.path.join(golden_dir, "c4_sh.npz"))
+    R = 480
+    opd_in = c4_test_opd(R)
+    sig64 = None
+    for dtype, n_envs, tol_sig, tol_frame, tol_opd in (("f64", 2, 1e-8, 1e-9, 1e-15), ("f32", 512, 2e-3, 5e-5, 5e-11)):
+        env = BatchedAOEnv(n_envs=n_envs, device=0, dtype=dtype, env_seed_stride=0)
+        try:
+            env.set_params(C4, camera="ideal", wfs_type="shackhartmann")
+            assert env.R == R and env.nValidAct == 5209 and env.nSignal == 10048 and env._atm_tables.n_outer == 1940
+            ns, nv = 80, env._sh_tables.nValid
+            if dtype == "f64":
+                assert np.array_equal(env.dm_mask.reshape(-1).astype(bool), g["validAct"])
+                assert np.array_equal(env._sh_tables.valid_2d, g["valid_subap"])
+                ref2d, valid = g["reference_slopes_maps"], g["valid_subap"]
+                np.testing.assert_allclose(env.reference_centroids[:nv], ref2d[:ns][valid], atol=1e-12)
+                np.testing.assert_allclose(env.reference_centroids[nv:], ref2d[ns:][valid], atol=1e-12)
+                np.testing.assert_allclose(env.slopes_units, float(g["slopes_units"]), rtol=1e-9)
+            # (a) one measurement of the recorded wave-front
+            env._shard.set_atm_opd(np.broadcast_to(opd_in.reshape(1, -1), (n_envs, R * R)))
+            env._shard.set_coefs(np.broadcast_to(g["coefs"][None], (n_envs, 5209)))
+            env.measure()
+            sig = env._shard.download(L.B_SIGNAL, (n_envs, env.nSignal))
+            frame = env._shard.download(L.B_FRAME, (n_envs, R, R))
+            opd = env._shard.download(L.B_PHASE, (n_envs, R, R)) * (env.src_wavelength / (2 * np.pi))
+            for k in (0, n_envs - 1):
+                np.testing.assert_allclose(opd[k][::16], g["opd_res_rows"], atol=tol_opd)
+                np.testing.assert_allclose(sig[k], g["signal"], atol=tol_sig)
+                np.testing.assert_allclose(frame[k][::8], g["frame_rows"], atol=tol_frame * float(g["frame_max"]))
+                np.testing.assert_allclose(frame[k].sum(axis=0), g["frame_colsum"], rtol=1e-4 if dtype == "f32" else 1e-9)
+            assert np.array_equal(sig[0], sig[-1]) and np.array_equal(frame[0], frame[-1])
+            if dtype == "f64":
+                sig64 = sig[0].copy()
+                # (b) ring extrusion on the device vs the oracle's A, B (float64 shard, 2 envs)
+                geom = O.LayerGeometry(R, 39.0, 30.0)
+                A_, B_ = geom.AB(0.13)
+                at = env._atm_tables
+                np.testing.assert_allclose(at.A, A_, atol=1e-9 * np.abs(A_).max())
+                np.testing.assert_allclose(at.B, B_, atol=1e-9 * np.abs(B_).max())
+                env.generate_new_phase_screen(17)              # draws the first ring of the new screens: X = A Z + B xi
+                zx = env._shard.download(L.B_XI, (n_envs, at.n_inner + at.n_outer))
+                scr = env._shard.download(L.B_SCREEN, (1, n_envs, at.S, at.S))[0]
+                for k in range(n_envs):
+                    np.testing.assert_allclose(zx[k, :at.n_inner], scr[k][at.inner_mask], atol=0)     # Z = the two inner rings
+                    want = A_ @ zx[k, :at.n_inner] + B_ @ zx[k, at.n_inner:]
+                    np.testing.assert_allclose(scr[k][at.outer_mask], want, atol=1e-9)
+                    rs = np.random.RandomState(17 + 0)          # ring RandomState: seed + 1000 * layer (layer 0)
+                    np.testing.assert_allclose(zx[k, at.n_inner:], rs.normal(size=at.n_outer), atol=4e-15)
+            else:
+                np.testing.assert_allclose(sig[0], sig64, atol=tol_sig)
+                # (c) 512 envs through six closed-loop steps (0.23 px per frame along x: one ring extrusion)
+                _assert_batch_invariant(env, 6)
+                buff = env._shard.get_buff(1)
+                assert abs(buff[0, 0]) < 1 and env._shard.download(L.B_XI, (n_envs, env._atm_tables.n_inner + 1940)).any()
+        finally:
+            env.close()

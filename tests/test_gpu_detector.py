@@ -14,7 +14,7 @@ SMALL = dict(diameter=3.2, nSubaperture=8, nPixelPerSubap=6, r0=0.13, L0=30.0, w
 def _env(n, **kw):
     from rlao_amd.env import BatchedAOEnv
     env = BatchedAOEnv(n_envs=n, device=0, dtype="f32", **kw)
-    env.set_params(SMALL, wfs_type="shackhartmann")
+    env.set_params(SMALL, camera="ideal", wfs_type="shackhartmann")
     env.env_seed_stride = 0                       # the same atmosphere in every env: frames differ by noise only
     env.generate_new_phase_screen(7)
     env.dm.coefs = 0

@@ -11,7 +11,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["tiny_sh", "tiny_fastwind", "tiny_3layer", "small_sh", "c2_sh", "tiny_pyr", "tiny_pyr_mod", "papyrus_pyr"]
+# c3_pyr / c5_mcao: BASELINE.json configs[2] / configs[4] at their real per-env size (8 m 40x40 Pyramid, nRes 528; 3 layers + 2 DMs)
+CASES = ["tiny_sh", "tiny_fastwind", "tiny_3layer", "small_sh", "c2_sh", "tiny_pyr", "tiny_pyr_mod", "papyrus_pyr", "c3_pyr", "c5_mcao"]
 
 # Stated tolerances of the step outputs (north_star: "within a stated fp32 tolerance"), absolute unless *_rel.
 # obs is in micrometres of DM stroke (|obs| ~ 0.05-1), residual/total in nm rms (~100-2000), strehl in [0, 1],
@@ -52,7 +53,26 @@ def test_mt19937_legacy_normal_stream(lib):
         np.testing.assert_allclose(out, want, rtol=0, atol=4e-15)
 
 
-def _replay(env, g, tol, n_envs_seeds):
+_OBSERVED = {}
+
+
+def _close(got, want, key, tol, label, rel_key=None, **kw):
+    """assert_allclose with the stated tolerance, recording the largest error seen per quantity: AO_PARITY_REPORT=<file> dumps
+    them as JSON (how the tolerances above were set: ~10x the maxima measured on MI355X)."""
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    err = float(np.abs(got - want).max()) if got.size else 0.0
+    scale = kw.pop("scale", 1.0)
+    rec = _OBSERVED.setdefault(label, {})
+    rec[key] = max(rec.get(key, 0.0), err / scale)
+    path = os.environ.get("AO_PARITY_REPORT")
+    if path:
+        import json
+        with open(path, "w") as f:
+            json.dump(_OBSERVED, f, indent=1, sort_keys=True)
+    np.testing.assert_allclose(got, want, atol=tol[key] * scale, rtol=tol.get(rel_key, 0) if rel_key else 0, **kw)
+
+
+def _replay(env, g, tol, n_envs_seeds, label="?"):
     """Drives `env` (n_envs = len(seeds)) through the recorded episodes and returns nothing; asserts."""
     import torch
     seeds = [int(s) for s in n_envs_seeds]
@@ -64,10 +84,10 @@ def _replay(env, g, tol, n_envs_seeds):
     obs0 = env.reset_soft().cpu().numpy()
     T = len(g[f"s{seeds[0]}_actions"])
     for k, s in enumerate(seeds):
-        np.testing.assert_allclose(obs0[k], g[f"s{s}_obs0"], atol=tol["obs"])
+        _close(obs0[k], g[f"s{s}_obs0"], "obs", tol, label)
     scr = env._shard.download(0, (env.param.nLayer, env.n_envs, env._atm_tables.S, env._atm_tables.S))
     for k, s in enumerate(seeds):
-        np.testing.assert_allclose(scr[:, k], g[f"s{s}_mapShift0"], atol=tol["screen"])
+        _close(scr[:, k], g[f"s{s}_mapShift0"], "screen", tol, label)
     for i in range(T):
         act = torch.as_tensor(np.stack([g[f"s{s}_actions"][i] for s in seeds]))
         obs, frame, rew, sr, done, info = env.step(i, act)
@@ -76,26 +96,25 @@ def _replay(env, g, tol, n_envs_seeds):
         coefs = env._shard.download(2, (env.n_envs, env.nValidAct))
         for k, s in enumerate(seeds):
             p = f"s{s}_"
-            np.testing.assert_allclose(sig[k], g[p + "signal"][i], atol=tol["signal"], err_msg=f"signal step {i}")
-            np.testing.assert_allclose(obs[k], g[p + "obs"][i], atol=tol["obs"], err_msg=f"obs step {i}")
+            _close(sig[k], g[p + "signal"][i], "signal", tol, label, err_msg=f"signal step {i}")
+            _close(obs[k], g[p + "obs"][i], "obs", tol, label, err_msg=f"obs step {i}")
             np.testing.assert_allclose(rew[k], g[p + "reward"][i], rtol=tol["reward_rel"], atol=tol["obs"])
-            np.testing.assert_allclose(sr[k], g[p + "strehl"][i], atol=tol["strehl"])
+            _close(sr[k], g[p + "strehl"][i], "strehl", tol, label)
             np.testing.assert_allclose(coefs[k], g[p + "coefs"][i], atol=1e-12, rtol=5e-6)
             full = {int(t): q for q, t in enumerate(g[p + "full_steps"])}
             if i in full:
                 q = full[i]
                 opd_atm = env._shard.download(1, (env.n_envs, env.R, env.R))[k]
                 phase = env._shard.download(3, (env.n_envs, env.R, env.R))[k]
-                np.testing.assert_allclose(opd_atm * env.pupil, g[p + "opd_atm"][q], atol=tol["opd_m"])
-                np.testing.assert_allclose(phase * env.src_wavelength / (2 * np.pi), g[p + "opd_res"][q], atol=tol["opd_m"])
-                fmax = g[p + "frame"][q].max()
-                np.testing.assert_allclose(frame[k], g[p + "frame"][q], atol=tol["frame_rel"] * fmax)
+                _close(opd_atm * env.pupil, g[p + "opd_atm"][q], "opd_m", tol, label)
+                _close(phase * env.src_wavelength / (2 * np.pi), g[p + "opd_res"][q], "opd_m", tol, label)
+                _close(frame[k], g[p + "frame"][q], "frame_rel", tol, label, scale=float(g[p + "frame"][q].max()))
     tot, res = env.total, env.residual
     if env.n_envs == 1:
         tot, res = tot[:, None], res[:, None]
     for k, s in enumerate(seeds):
-        np.testing.assert_allclose(tot[:T, k], g[f"s{s}_total"], atol=tol["rms_nm"])
-        np.testing.assert_allclose(res[:T, k], g[f"s{s}_residual"], atol=tol["rms_nm"])
+        _close(tot[:T, k], g[f"s{s}_total"], "rms_nm", tol, label)
+        _close(res[:T, k], g[f"s{s}_residual"], "rms_nm", tol, label)
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
@@ -108,7 +127,10 @@ def test_golden_replay(name, dtype, golden_dir):
     try:
         pyr = "cfg_wfs" in g
         extra = dict(modulation=float(g["cfg_modulation"]), psfCentering=bool(g["cfg_centering"])) if pyr else {}
-        env.set_params(_params(g, **extra), wfs_type="pyramid" if pyr else "shackhartmann", m2c=g["m2c"])
+        second = dict(nSubaperture=int(g["cfg_second_nsub"])) if "cfg_second_nsub" in g else None
+        env.set_params(_params(g, **extra), camera="ideal", wfs_type="pyramid" if pyr else "shackhartmann", m2c=g["m2c"],
+                       second_dm=second)
+        assert np.array_equal(env.dm_mask.reshape(-1).astype(bool), g["validAct"])
         # calibration is always measured in float64 on the GPU
         ns = int(g["cfg_nsub"])
         if pyr:
@@ -123,8 +145,45 @@ def test_golden_replay(name, dtype, golden_dir):
             np.testing.assert_allclose(env.reference_centroids[:nv], ref2d[:ns][valid], atol=1e-12)
             np.testing.assert_allclose(env.reference_centroids[nv:], ref2d[ns:][valid], atol=1e-12)
             np.testing.assert_allclose(env.slopes_units, float(g["slopes_units"]), rtol=1e-9)
-        np.testing.assert_allclose(env.imat, g["imat"], atol=2e-9 * np.abs(g["imat"]).max())
-        np.testing.assert_allclose(env.reconstructor, g["recon"], atol=1e-7 * np.abs(g["recon"]).max())
-        _replay(env, g, F64_TOL if dtype == "f64" else F32_TOL, seeds)
+        if "imat" in g:
+            np.testing.assert_allclose(env.imat, g["imat"], atol=2e-9 * np.abs(g["imat"]).max())
+            np.testing.assert_allclose(env.reconstructor, g["recon"], atol=1e-7 * np.abs(g["recon"]).max())
+        else:
+            # 1353 x 2608 interaction matrix: three whole columns, two random combinations of all columns, the Frobenius norm,
+            # its product with the M2C and the modal command matrix built from it
+            scale = np.abs(g["imat_cols"]).max()
+            np.testing.assert_allclose(env.imat[:, g["imat_cols_idx"]], g["imat_cols"], atol=2e-9 * scale)
+            np.testing.assert_allclose(env.imat @ g["imat_probe_in"], g["imat_probe_out"], atol=2e-9 * np.abs(g["imat_probe_out"]).max())
+            np.testing.assert_allclose(np.linalg.norm(env.imat), float(g["imat_fro"]), rtol=1e-9)
+            np.testing.assert_allclose(env.imat @ g["m2c"], g["modal_imat"], atol=2e-9 * np.abs(g["modal_imat"]).max())
+            np.testing.assert_allclose(env.modal_CM, g["modal_cm"], atol=1e-7 * np.abs(g["modal_cm"]).max())
+        _replay(env, g, F64_TOL if dtype == "f64" else F32_TOL, seeds, label=f"{name}-{dtype}")
     finally:
+        env.close()
+
+
+def test_second_episode_keeps_dm_prev(golden_dir):
+    """MAIN/PO4AO/mbrl.py:49-55 run twice on ONE env: the prologue's ``env.dm.coefs = 0`` does not clear the env's dm_prev
+    (MAIN/OOPAOEnv/OOPAOEnv.py:314, 508-509), so step 0 of the second episode applies leak * (last command of the first) + action.
+    Reference recording: tests/golden/two_episodes.npz; fused step kernel (float32) and the separate kernels (float64)."""
+    import torch
+    from rlao_amd import _lib as L
+    from rlao_amd.env import BatchedAOEnv
+    g = np.load(os.path.join(golden_dir, "two_episodes.npz"))
+    for dtype, tol in (("f64", F64_TOL), ("f32", F32_TOL)):
+        env = BatchedAOEnv(n_envs=1, device=0, dtype=dtype)
+        env.set_params(_params(g), camera="ideal", wfs_type="shackhartmann", m2c=g["m2c"])
+        for tag, seed in (("e1_", 5), ("e2_", 0)):
+            env.atm.generateNewPhaseScreen(seed)
+            env.dm.coefs = 0
+            env.tel * env.dm * env.wfs
+            obs = env.reset_soft()
+            np.testing.assert_allclose(obs[0].cpu().numpy(), g[tag + "obs0"], atol=tol["obs"])
+            for i, act in enumerate(g[tag + "actions"]):
+                obs, _, rew, sr, _, _ = env.step(i, torch.as_tensor(act))
+                np.testing.assert_allclose(obs[0].cpu().numpy(), g[tag + "obs"][i], atol=tol["obs"], err_msg=f"{tag} obs step {i}")
+                np.testing.assert_allclose(env.dm.coefs, g[tag + "coefs"][i], atol=1e-12, rtol=5e-6, err_msg=f"{tag} coefs step {i}")
+                np.testing.assert_allclose(float(sr[0]), g[tag + "strehl"][i], atol=tol["strehl"])
+            dm_prev = env._shard.download(L.B_DM_PREV, (1, env.nValidAct))[0]
+            np.testing.assert_allclose(dm_prev, g[tag + "dm_prev_end"], atol=1e-12, rtol=5e-6)
         env.close()
