@@ -782,6 +782,22 @@ class BatchedAOEnv:
             return float(avg[0]), float(std[0])
         return avg, std
 
+    @property
+    def dm_prev(self):
+        """The leaky integrator's state (MAIN/OOPAOEnv/OOPAOEnv.py:314, 508-509): ``step`` computes
+        ``dm.coefs = dm_prev * leak + action`` and stores it back.  ``env.dm.coefs = 0`` does not clear it (the trainers' episode
+        prologue leaves it as the previous episode ended, as in the reference); ``env.dm_prev = 0`` does."""
+        return self._fetch(L.B_DM_PREV, (self.nValidAct,))
+
+    @dm_prev.setter
+    def dm_prev(self, val):
+        v = np.zeros((self.n_envs, self.nValidAct)) if np.isscalar(val) and val == 0 else np.asarray(val, dtype=np.float64)
+        if v.shape == (self.nValidAct,):
+            v = np.broadcast_to(v, (self.n_envs, self.nValidAct))
+        if v.shape != (self.n_envs, self.nValidAct):
+            raise ValueError(f"dm_prev must be 0 or have shape ({self.nValidAct},) or ({self.n_envs}, {self.nValidAct})")
+        self._shard.upload_state(L.B_DM_PREV, v, self._stream())
+
     def get_strehl(self):
         return float(self._strehl[0]) if self.n_envs == 1 else self._strehl.clone()
 

@@ -138,6 +138,7 @@ class HistoryEnv:
         e = self._env
         e.atm.generateNewPhaseScreen(seed)
         e.dm.coefs = 0
+        e.dm_prev = 0                                           # reset() also clears the integrator state (OOPAOEnv_VPG.py:120-121)
         e.tel * e.dm * e.wfs
         obs = _torch().as_tensor(e.reset_soft(), dtype=_torch().float32)
         self._alloc()

@@ -19,6 +19,7 @@ def _run(env, steps, seed, gain=0.5):
     import torch
     env.generate_new_phase_screen(seed)
     env.dm.coefs = 0
+    env.dm_prev = 0                                             # a fresh episode of a fresh env (the prologue alone keeps dm_prev)
     env.measure()
     obs = env.reset_soft()
     out = []
@@ -110,6 +111,7 @@ def test_run_integrator_equals_stepping():
     a = _run(env, 10, 3, gain=0.4)
     env.generate_new_phase_screen(3)
     env.dm.coefs = 0
+    env.dm_prev = 0
     env.measure()
     env.reset_soft()
     obs, rew, sr = env.run_integrator(0, 10)
@@ -121,6 +123,7 @@ def test_run_integrator_equals_stepping():
     ret = torch.zeros(4, device=env.device, dtype=env.tdtype)
     env.generate_new_phase_screen(3)
     env.dm.coefs = 0
+    env.dm_prev = 0
     env.measure()
     env.reset_soft()
     env.accumulate_returns(ret)
@@ -381,6 +384,7 @@ def test_history_env_on_the_device():
     # the same episode by hand
     env.atm.generateNewPhaseScreen(3)
     env.dm.coefs = 0
+    env.dm_prev = 0                                             # (the prologue alone keeps the previous episode's last command)
     env.tel * env.dm * env.wfs
     obs = env.reset_soft()
     assert torch.equal(obs, first)

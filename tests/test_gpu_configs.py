@@ -29,6 +29,7 @@ def _episode(env, steps, seed, gain=0.5):
     import torch
     env.generate_new_phase_screen(seed)
     env.dm.coefs = 0
+    env.dm_prev = 0                                             # a fresh episode of a fresh env (the prologue alone keeps dm_prev)
     env.measure()
     obs = env.reset_soft()
     out = []
