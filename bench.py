@@ -248,14 +248,9 @@ class Timer:
 def set_camera(env, camera):
     cam = env.wfs.cam
     if camera == "razor":
-        cam.sensor, cam.FWC, cam.bits, cam.QE, cam.darkCurrent, cam.integrationTime = "CMOS", 10000, 10, 0.56, 5, 1 / 500
-        cam.photonNoise, cam.readoutNoise = True, 14
-    elif camera == "papyrus":
-        cam.FWC, cam.bits, cam.QE, cam.darkCurrent, cam.readoutNoise = None, None, 1, 0, 0
-        cam.photonNoise = True
+        cam.configure(sensor="CMOS", FWC=10000, bits=10, QE=0.56, darkCurrent=5, integrationTime=1 / 500, photonNoise=True, readoutNoise=14)
     else:
-        cam.FWC, cam.bits, cam.QE, cam.darkCurrent, cam.readoutNoise = None, None, 1, 0, 0
-        cam.photonNoise = False
+        cam.configure(sensor="CCD", FWC=None, bits=None, QE=1, darkCurrent=0, readoutNoise=0, photonNoise=camera == "papyrus")
 
 
 def start_episode(env, seed=17):

@@ -51,10 +51,21 @@ __global__ void __launch_bounds__(256) k_pyr_rows(const PyrArgs<T> a) {
                 if (tt) ang += tt[p];
                 // centred mask: the field is multiplied by exp(-i pi (N+1)/N (x + y)) on the padded grid (Pyramid.py:294, 486)
                 // the angle pi (N+1) k / N is reduced mod 2 pi in integers (k up to 2N would cost float32 1e-4 rad)
-                if (a.phasor_mult) ang -= pi_over_n * (T)((a.phasor_mult * (xg + y0 + r + a.off)) % two_n);
+                const T pang = a.phasor_mult ? pi_over_n * (T)((a.phasor_mult * (xg + y0 + r + a.off)) % two_n) : (T)0;
                 T s, c;
-                sincos_g<T>(ang, &s, &c);
-                v = {am * c, am * s};
+                if (sizeof(T) == 8 && a.phasor_mult) {
+                    // float64: field and phasor multiplied as two complex numbers, as the reference does (support * phasor).
+                    // Folding the phasor's angle into the phase rounds it to ulp(|phase|): the WFS calibration measures a
+                    // wave-front of 1 m of piston (Pyramid.py:462-466; 8e6 rad, ulp 1e-9 rad), which showed as 1e-9 in the
+                    // reference slopes and in the interaction matrix.
+                    T ps, pc;
+                    sincos_g<T>(ang, &s, &c);
+                    sincos_g<T>(pang, &ps, &pc);
+                    v = {am * (c * pc + s * ps), am * (s * pc - c * ps)};
+                } else {
+                    sincos_g<T>(ang - pang, &s, &c);
+                    v = {am * c, am * s};
+                }
             }
         }
         A[r * NP + fpad(xg)] = v;

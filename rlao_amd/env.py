@@ -242,6 +242,17 @@ class _Cam:
         if name in self._FIELDS:
             self._e._push_detector()
 
+    def configure(self, **fields):
+        """Several camera fields at once, pushed to the device together (setting them one by one pushes every intermediate
+        combination, and e.g. ``bits`` without ``FWC`` is not a camera the library builds)."""
+        for k, v in fields.items():
+            if k not in self._FIELDS:
+                raise AttributeError(f"unknown camera field {k!r}")
+            if k == "sensor" and v not in ("EMCCD", "CCD", "CMOS"):
+                raise ValueError("Sensor must be 'EMCCD', 'CCD', or 'CMOS'")
+            object.__setattr__(self, k, v)
+        self._e._push_detector()
+
     @property
     def frame(self):
         return self._e._fetch(L.B_FRAME, (self._e.cam_res, self._e.cam_res))
@@ -388,7 +399,7 @@ class BatchedAOEnv:
         self.param_file, self.oopao_path = param_file, oopao_path
 
     def set_params(self, args=None, wfs_type="pyramid", modal_basis="zernike", gainCL=0.5, m2c=None, second_dm=None,
-                   camera="papyrus", **kw):
+                   camera="papyrus", atm_AB=None, **kw):
         """Builds the loop (MAIN/OOPAOEnv/OOPAOEnv.py:93-385).  ``wfs_type`` is "pyramid" (the reference's default,
         Papyrus) or "shackhartmann" (OOPAOEnvRazor.py:232-238).  ``second_dm=dict(nSubaperture=n)`` chains a second DM of
         that pitch behind the first (``tel*dm1*dm2*wfs``, BASELINE configs[4]): commands, observations and actions then
@@ -414,6 +425,16 @@ class BatchedAOEnv:
         self.pupil = calib.telescope_pupil(self.R, p.centralObstruction)
         self.src_wavelength, self.nPhoton = calib.source(p.opticalBand, p.magnitude)
         self._atm_tables = calib.AtmosphereTables(p)
+        if atm_AB is not None:
+            # the ring-extrusion operators handed over instead of recomputed: A = ZXt^T pinv(ZZt) goes through the pseudo-inverse
+            # of a covariance matrix of condition ~1e9, whose result differs between CPUs / LAPACK builds at the 1e-9 .. 1e-7 level
+            # (the parity tests inject the recorded operators to separate that from the device arithmetic)
+            A_, B_ = (np.asarray(x, dtype=np.float64) for x in atm_AB)
+            at = self._atm_tables
+            if A_.shape != at.A.shape or B_.shape != at.B.shape:
+                raise ValueError(f"atm_AB must have shapes {at.A.shape} and {at.B.shape}")
+            at.A, at.B = A_, B_
+            at.AB = np.ascontiguousarray(np.concatenate([A_, B_], axis=1))
         self._dm_tables = dmt = (calib.DMTables(p) if not second_dm else
                                  calib.CompositeDM(p, int(second_dm["nSubaperture"])))
         self._dm_separable = 1 if dmt.gx is not None else 0
@@ -468,15 +489,11 @@ class BatchedAOEnv:
         self.atm, self.dm, self.tel, self.wfs = _AtmProxy(self), _DmProxy(self), _TelProxy(self), _WfsProxy(self)
         self.wfs.tag = "shackHartmann" if self.wfs_type == "sh" else "pyramid"
         pre, post = CAMERAS[camera]
-        for k, v in pre.items():
-            object.__setattr__(self.wfs.cam, k, p.samplingTime if v == "samplingTime" else v)
-        self._push_detector()
+        self.wfs.cam.configure(**{k: (p.samplingTime if v == "samplingTime" else v) for k, v in pre.items()})
         # flat measurement, then the initial screens (MAIN/OOPAOEnv/OOPAOEnv.py:312-322)
         self.measure()
         self.generate_new_phase_screen(10)
-        for k, v in post.items():                                   # OOPAOEnv.py:379 / OOPAOEnvRazor.py:332-333
-            object.__setattr__(self.wfs.cam, k, v)
-        self._push_detector()
+        self.wfs.cam.configure(**post)                              # OOPAOEnv.py:379 / OOPAOEnvRazor.py:332-333
         return self
 
     def _make_shard(self, n_env, dtype, n_layer, max_group, cam_pre=False) -> Shard:

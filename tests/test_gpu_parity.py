@@ -25,6 +25,9 @@ CASES = ["tiny_sh", "tiny_fastwind", "tiny_3layer", "small_sh", "c2_sh", "tiny_p
 #   matches the reference to 1e-13.
 F32_TOL = dict(obs=3e-5, reward_rel=1e-4, strehl=1e-5, rms_nm=3e-3, signal=6e-4, opd_m=5e-11, frame_rel=5e-5, screen=5e-4)
 F64_TOL = dict(obs=1e-6, reward_rel=1e-6, strehl=1e-6, rms_nm=1e-4, signal=5e-5, opd_m=5e-12, frame_rel=5e-6, screen=2e-5)
+#   float64 shards with the golden's OWN A, B injected (the fixtures of the R <= 48 cases hold them): the host-side pinv is out of
+#   the comparison and what is left is the device arithmetic against NumPy's -- re-ordering noise.
+F64_SAME_OPERATOR_TOL = dict(obs=1e-8, reward_rel=1e-9, strehl=1e-9, rms_nm=1e-6, signal=1e-7, opd_m=1e-15, frame_rel=1e-9, screen=1e-9)
 
 
 def _params(g, **kw):
@@ -117,19 +120,29 @@ def _replay(env, g, tol, n_envs_seeds, label="?"):
         _close(res[:T, k], g[f"s{s}_residual"], "rms_nm", tol, label)
 
 
-@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("dtype", ["f64", "f32", "f64-refAB"])
 @pytest.mark.parametrize("name", CASES)
 def test_golden_replay(name, dtype, golden_dir):
     from rlao_amd.env import BatchedAOEnv
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     seeds = list(g["cfg_seeds"])
+    label = f"{name}-{dtype}"
+    inject = dtype == "f64-refAB"
+    if inject:
+        if "A" not in g:
+            pytest.skip("the fixture holds only probes of A and B (large geometry)")
+        dtype = "f64"
     env = BatchedAOEnv(n_envs=len(seeds), device=0, dtype=dtype)
     try:
         pyr = "cfg_wfs" in g
         extra = dict(modulation=float(g["cfg_modulation"]), psfCentering=bool(g["cfg_centering"])) if pyr else {}
         second = dict(nSubaperture=int(g["cfg_second_nsub"])) if "cfg_second_nsub" in g else None
         env.set_params(_params(g, **extra), camera="ideal", wfs_type="pyramid" if pyr else "shackhartmann", m2c=g["m2c"],
-                       second_dm=second)
+                       second_dm=second, atm_AB=(g["A"], g["B"]) if inject else None)
+        # how far this host's A = ZXt^T pinv(ZZt) is from the one the reference computed in the build container (recorded)
+        at = env._atm_tables
+        dA = np.abs(at.A - g["A"]).max() if "A" in g else np.abs(at.A @ g["A_probe_in"] - g["A_probe_out"]).max()
+        _OBSERVED.setdefault(label, {})["host_A_vs_golden"] = float(dA)
         assert np.array_equal(env.dm_mask.reshape(-1).astype(bool), g["validAct"])
         # calibration is always measured in float64 on the GPU
         ns = int(g["cfg_nsub"])
@@ -157,7 +170,7 @@ def test_golden_replay(name, dtype, golden_dir):
             np.testing.assert_allclose(np.linalg.norm(env.imat), float(g["imat_fro"]), rtol=1e-9)
             np.testing.assert_allclose(env.imat @ g["m2c"], g["modal_imat"], atol=2e-9 * np.abs(g["modal_imat"]).max())
             np.testing.assert_allclose(env.modal_CM, g["modal_cm"], atol=1e-7 * np.abs(g["modal_cm"]).max())
-        _replay(env, g, F64_TOL if dtype == "f64" else F32_TOL, seeds, label=f"{name}-{dtype}")
+        _replay(env, g, F64_SAME_OPERATOR_TOL if inject else (F64_TOL if dtype == "f64" else F32_TOL), seeds, label=label)
     finally:
         env.close()
 
