@@ -123,6 +123,18 @@ def _limit_threads():
         return None
 
 
+def available_cores() -> int:
+    """Cores this process may really use: the affinity mask, cut down to the cgroup CPU quota when there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
 def _cpu_worker(conn, camera, budget_s):
     _limit_threads()
     env = _oracle_env(camera)
@@ -144,7 +156,7 @@ def cpu_baseline(camera: str, budget_s: float, all_cores: bool):
                      f"{dt:.1f} s"}
     if all_cores:
         import multiprocessing as mp
-        P = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        P = available_cores()
         mpc = mp.get_context("fork")                           # forked before torch / HIP are imported in this process
         procs = []
         for _ in range(P):

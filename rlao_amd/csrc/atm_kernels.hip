@@ -76,14 +76,17 @@ __device__ inline void mt_twist(uint32_t* s) {
     __syncthreads();
 }
 
+// mt_state_out / mt_pos_out: where the advanced stream is stored (== the inputs: in place; another buffer: the draw is
+// speculative -- the ring look-ahead of env.hip -- and the caller commits it by swapping the buffers)
 template <typename T>
-__device__ inline void mt_normal_body(uint32_t* __restrict__ mt_state, int* __restrict__ mt_pos, T* __restrict__ zx, int K,
-                                      int n_inner, int n_outer, int e) {
+__device__ inline void mt_normal_body(const uint32_t* mt_state, const int* mt_pos, uint32_t* mt_state_out, int* mt_pos_out,
+                                      T* __restrict__ zx, int K, int n_inner, int n_outer, int e) {
     __shared__ uint32_t s[kMtN];
     __shared__ int scan[256];
     __shared__ int sh_pos, sh_got, sh_stop;
     const int t = threadIdx.x;
-    uint32_t* gs = mt_state + (size_t)e * kMtN;
+    const uint32_t* gs = mt_state + (size_t)e * kMtN;
+    uint32_t* gso = mt_state_out + (size_t)e * kMtN;
     for (int i = t; i < kMtN; i += 256) s[i] = gs[i];
     if (t == 0) {
         sh_pos = mt_pos[e];
@@ -148,34 +151,35 @@ __device__ inline void mt_normal_body(uint32_t* __restrict__ mt_state, int* __re
         __syncthreads();
     }
     __syncthreads();
-    for (int i = t; i < kMtN; i += 256) gs[i] = s[i];
-    if (t == 0) mt_pos[e] = sh_pos;
+    for (int i = t; i < kMtN; i += 256) gso[i] = s[i];
+    if (t == 0) mt_pos_out[e] = sh_pos;
 }
 
 template <typename T>
 __global__ void __launch_bounds__(256) k_mt_normal(uint32_t* __restrict__ mt_state, int* __restrict__ mt_pos,
                                                    T* __restrict__ zx, int K, int n_inner, int n_outer) {
-    mt_normal_body<T>(mt_state, mt_pos, zx, K, n_inner, n_outer, blockIdx.x);
+    mt_normal_body<T>(mt_state, mt_pos, mt_state, mt_pos, zx, K, n_inner, n_outer, blockIdx.x);
 }
 
 // One launch for the two independent halves of the ring operand [Z | xi] of env blockIdx.y:
 // blockIdx.x == 0 gathers Z, blockIdx.x == 1 draws the n_outer innovations xi of the layer's MT19937 stream.
 template <typename T>
 __global__ void __launch_bounds__(256) k_ring_prepare(const T* __restrict__ map, T* __restrict__ zx,
-                                                      const int* __restrict__ inner_idx, uint32_t* __restrict__ mt_state,
-                                                      int* __restrict__ mt_pos, int S, int n_inner, int n_outer, int K,
-                                                      int sx, int sy, int oy, int ox) {
+                                                      const int* __restrict__ inner_idx, const uint32_t* mt_state,
+                                                      const int* mt_pos, uint32_t* mt_state_out, int* mt_pos_out, int S,
+                                                      int n_inner, int n_outer, int K, int sx, int sy, int oy, int ox) {
     const int e = blockIdx.y;
     if (blockIdx.x == 0) gather_ring<T>(map, zx, inner_idx, S, n_inner, K, sx, sy, oy, ox, e, threadIdx.x, 256);
-    else mt_normal_body<T>(mt_state, mt_pos, zx, K, n_inner, n_outer, e);
+    else mt_normal_body<T>(mt_state, mt_pos, mt_state_out, mt_pos_out, zx, K, n_inner, n_outer, e);
 }
 
 template <typename T>
-int launch_ring_prepare(const T* map, T* zx, const int* inner_idx, uint32_t* mt_state, int* mt_pos, int n_env, int S,
-                        int n_inner, int n_outer, int K, int sx, int sy, int oy, int ox, hipStream_t st) {
+int launch_ring_prepare(const T* map, T* zx, const int* inner_idx, const uint32_t* mt_state, const int* mt_pos,
+                        uint32_t* mt_state_out, int* mt_pos_out, int n_env, int S, int n_inner, int n_outer, int K, int sx, int sy,
+                        int oy, int ox, hipStream_t st) {
     if (n_outer % 2) return fail("mt_normal: n_outer=%d must be even", n_outer);
-    hipLaunchKernelGGL(k_ring_prepare<T>, dim3(2, n_env), dim3(256), 0, st, map, zx, inner_idx, mt_state, mt_pos, S, n_inner,
-                       n_outer, K, sx, sy, oy, ox);
+    hipLaunchKernelGGL(k_ring_prepare<T>, dim3(2, n_env), dim3(256), 0, st, map, zx, inner_idx, mt_state, mt_pos, mt_state_out,
+                       mt_pos_out, S, n_inner, n_outer, K, sx, sy, oy, ox);
     AO_HIP(hipGetLastError());
     return 0;
 }
@@ -275,8 +279,8 @@ int launch_minmax(const T* maps, T* minmax, int n_env, int S, hipStream_t st) {
 }
 
 #define INST(T)                                                                                                    \
-    template int launch_ring_prepare<T>(const T*, T*, const int*, uint32_t*, int*, int, int, int, int, int, int, int, \
-                                        int, int, hipStream_t);                                                    \
+    template int launch_ring_prepare<T>(const T*, T*, const int*, const uint32_t*, const int*, uint32_t*, int*, int, int, int, \
+                                        int, int, int, int, int, int, hipStream_t);                                \
     template int launch_mt_normal<T>(uint32_t*, int*, T*, int, int, int, int, hipStream_t);                        \
     template int launch_scatter_minmax<T>(T*, const T*, const int*, T*, int, int, int, int, int, int, int,         \
                                           hipStream_t);                                                            \

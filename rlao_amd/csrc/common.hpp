@@ -65,8 +65,9 @@ namespace ao {
 struct Env;  // host object, env.hpp
 
 template <typename T>
-int launch_ring_prepare(const T* map, T* zx, const int* inner_idx, uint32_t* mt_state, int* mt_pos, int n_env, int S,
-                        int n_inner, int n_outer, int K, int sx, int sy, int oy, int ox, hipStream_t st);
+int launch_ring_prepare(const T* map, T* zx, const int* inner_idx, const uint32_t* mt_state, const int* mt_pos,
+                        uint32_t* mt_state_out, int* mt_pos_out, int n_env, int S, int n_inner, int n_outer, int K, int sx, int sy,
+                        int oy, int ox, hipStream_t st);
 template <typename T>
 int launch_mt_normal(uint32_t* mt_state, int* mt_pos, T* zx, int n_env, int K, int n_inner, int n_outer,
                      hipStream_t st);

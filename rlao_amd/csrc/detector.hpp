@@ -7,8 +7,22 @@
 //   read-out noise  + round(N(0,1) * sigma)           :218-221
 //   ADC  trunc(frame / FWC * (2^bits - 1)), clipped to 2^bits - 1   :190-201
 // The reference seeds its generators from the wall clock (Detector.py:127-130): a noisy frame is reproducible only in
-// distribution.  Here every pixel draws from a counter-based Philox4x32-7 stream keyed by (seed) and indexed by
-// (pixel, global env index, frame counter): reproducible, independent of the batch layout and of the kernel variant.
+// distribution.  Here the random numbers come from counter-based Philox4x32-7 streams keyed by `seed` and indexed by (pixel
+// group, global env index, frame counter, purpose): reproducible, independent of the batch layout and of the kernel variant.
+//
+// Stream layout (the fused step kernel and k_detector draw the same numbers):
+//   * the frame is cut into QUADS of 4 pixels; one Philox call per (quad, purpose) serves its 4 pixels, slot s gets word s:
+//       purpose 0  photon noise of a faint pixel (lambda < kPtrsFrom): ONE uniform, inversion by sequential search (exact)
+//       purpose 1  dark shot noise: one uniform, the same inversion
+//       purpose 2  read-out noise: slots (0, 1) and (2, 3) share a Box-Muller pair (cos / sin branch)
+//   * a bright pixel (lambda >= kPtrsFrom) draws from a stream of its own, (pixel, env, frame, 16 + j): Hoermann's PTRS
+//     rejection sampler (exact; the algorithm NumPy's legacy generator uses), two uniforms per round.
+//   Quads: Shack-Hartmann frames with 6-pixel lenslets use the lane -> pixel map of the fused step kernel (a lane owns rows
+//   0..5 of the lenslet columns q and q + 3): rows 0..3 of a column are one quad, rows 4..5 of the columns c and c + 3 another.
+//   Any other frame: 4 consecutive pixels of a row.  A quad is named by the frame index of its slot-0 pixel.
+// Cost (why it is laid out like this): a Philox call is ~100 issue slots (its 32 x 32 multiplies are quarter rate); one call per
+// pixel and one data-dependent sampler per pixel (a wave runs both the faint and the bright branch, for as many rounds as
+// its slowest lane) made the camera cost more than the physics (round 1: step kernel 40 -> 92 us with photon noise).
 #pragma once
 #include "common.hpp"
 
@@ -31,37 +45,42 @@ struct Philox {
 __device__ inline void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
     Philox p{{c0, c1, c2, c3}, {k0, k1}};
 #pragma unroll
-    for (int i = 0; i < 7; ++i) p.round();                       // Philox4x32-7 (Salmon et al. 2011: 7 rounds pass BigCrush):
-                                                                 // 32-bit integer multiplies are quarter-rate on CDNA
+    for (int i = 0; i < 7; ++i) p.round();                       // Philox4x32-7 (Salmon et al. 2011: 7 rounds pass BigCrush)
     out[0] = p.c[0]; out[1] = p.c[1]; out[2] = p.c[2]; out[3] = p.c[3];
 }
 
 __device__ inline float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }   // (0, 1)
 
-// One pixel's stream: uniforms on demand, 4 per Philox call (a shift register: no dynamically indexed array, which
-// the compiler would place in scratch memory).
-struct PixelRng {
-    uint32_t c0, c1, c2, k0, k1, sub;
-    uint32_t b0, b1, b2, b3;
-    int have;
-    __device__ inline PixelRng(uint32_t pixel, uint32_t env, uint32_t frame, uint32_t s0, uint32_t s1)
-        : c0(pixel), c1(env), c2(frame), k0(s0), k1(s1), sub(0), b0(0), b1(0), b2(0), b3(0), have(0) {}
-    __device__ inline float next() {
-        if (have == 0) {
-            uint32_t o[4];
-            philox4x32(c0, c1, c2, sub++, k0, k1, o);
-            b0 = o[3]; b1 = o[2]; b2 = o[1]; b3 = o[0];        // handed out in the order o[3], o[2], o[1], o[0]
-            have = 4;
+constexpr float kPtrsFrom = 10.f;                              // PTRS is valid from lambda = 10 (NumPy switches there too)
+enum { kDrawPhoton = 0, kDrawDark = 1, kDrawReadout = 2, kDrawPixelStream = 16 };
+
+__device__ inline void quad_bits(uint32_t quad, uint32_t env, const DetectorCfg& d, uint32_t purpose, uint32_t (&o)[4]) {
+    philox4x32(quad, env + d.env_offset, d.frame_counter, purpose, d.seed_lo, d.seed_hi, o);
+}
+
+// 1 / k, k = lane + 1, held across the wave (the inversion walks k in lock-step: the reciprocal of the wave's k is one
+// v_readlane instead of a quarter-rate v_rcp per lane and step)
+__device__ inline float recip_table_lane() { return 1.0f / (float)((threadIdx.x & 63) + 1); }
+
+// Poisson(lam), lam < kPtrsFrom (any lam < ~20 is sampled correctly): inversion by sequential search with ONE uniform,
+// X = #{k >= 0 : u > F(k)}.  The lanes of a wave walk k together, 4 steps per vote; a lane that has found its X keeps
+// counting zeros.  64 steps cover the tail far below float32 resolution.  `active` lanes only (others: lam = 0 -> 0).
+__device__ inline float poisson_inversion(float lam, float u, float rtab) {
+    float p = __expf(-lam), cdf = p, k = 0.f;
+    for (int k0 = 0; k0 < 64; k0 += 4) {
+        if (!__any(u > cdf)) break;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            k += u > cdf ? 1.f : 0.f;                                         // X > t = k0 + j
+            p *= lam * __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rtab), k0 + j));   // P(t + 1) = P(t) lam / (t + 1)
+            cdf += p;
         }
-        const uint32_t v = b0;
-        b0 = b1; b1 = b2; b2 = b3;
-        --have;
-        return u01(v);
     }
-};
+    return k;
+}
 
 // log(k!) for integer-valued k >= 0.
-// (lgammaf costs ~10x more instructions, and the PTRS acceptance test below runs for every lit pixel of every frame.)
+// (lgammaf costs ~10x more instructions, and the PTRS acceptance test below runs for every bright pixel of every frame.)
 __device__ inline float log_factorial(float k) {
     // k >= 4: Stirling's series with three correction terms, |error| < 2e-8;  k = 0..3 from a 4-entry select
     const float kk = fmaxf(k, 4.f);
@@ -72,54 +91,57 @@ __device__ inline float log_factorial(float k) {
     return k < 4.f ? small : st;
 }
 
-// Poisson(lam): sequential inversion below 12 (exact, ~lam iterations), Hoermann's PTRS above (exact; the algorithm
-// NumPy's legacy generator uses for lam >= 10).
-__device__ inline float poisson(float lam, PixelRng& g) {
-    if (!(lam > 0.f)) return 0.f;
-    if (lam < 12.f) {
-        const float u = g.next();
-        float p = __expf(-lam), cdf = p;
-        int k = 0;
-        while (u > cdf && k < 200) {
-            ++k;
-            p *= lam * __builtin_amdgcn_rcpf((float)k);              // 1 ulp reciprocal: the term of the series to 1e-7
-            cdf += p;
-        }
-        return (float)k;
-    }
+// Poisson(lam), lam >= kPtrsFrom: Hoermann's PTRS (exact).  The pixel's own stream: call j gives the uniforms of rounds 2j, 2j+1.
+__device__ inline float poisson_ptrs(float lam, uint32_t pixel, uint32_t env, const DetectorCfg& d) {
     // (1-ulp hardware reciprocals / square root: an IEEE division expands to ~10 instructions, and the constants of the
     //  hat function do not need the last bit)
     const float slam = __builtin_amdgcn_sqrtf(lam), loglam = __logf(lam);
     const float b = 0.931f + 2.53f * slam, a = -0.059f + 0.02483f * b;
     const float invalpha = 1.1239f + 1.1328f * __builtin_amdgcn_rcpf(b - 3.4f), vr = 0.9277f - 3.6224f * __builtin_amdgcn_rcpf(b - 2.f);
     const float log_invalpha = __logf(invalpha);
-    for (int it = 0; it < 64; ++it) {
-        const float U = g.next() - 0.5f, V = g.next();
-        const float us = 0.5f - fabsf(U);
-        const float rus = __builtin_amdgcn_rcpf(us);
-        const float kf = floorf((2.f * a * rus + b) * U + lam + 0.43f);
-        if (us >= 0.07f && V <= vr) return kf;
-        if (kf < 0.f || (us < 0.013f && V > us)) continue;
-        if (__logf(V) + log_invalpha - __logf(a * rus * rus + b) <= -lam + kf * loglam - log_factorial(kf)) return kf;
+    float result = floorf(lam + 0.5f);
+    bool done = false;
+    for (uint32_t call = 0; call < 32; ++call) {
+        uint32_t o[4];
+        philox4x32(pixel, env + d.env_offset, d.frame_counter, kDrawPixelStream + call, d.seed_lo, d.seed_hi, o);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float U = u01(o[2 * h]) - 0.5f, V = u01(o[2 * h + 1]);
+            const float us = 0.5f - fabsf(U);
+            const float rus = __builtin_amdgcn_rcpf(us);
+            const float kf = floorf((2.f * a * rus + b) * U + lam + 0.43f);
+            bool acc = us >= 0.07f && V <= vr;                                   // squeeze: ~86 % of the draws end here
+            if (__any(!done && !acc)) {                                         // someone needs the full test: everyone evaluates it
+                const bool cand = !(kf < 0.f || (us < 0.013f && V > us));
+                const bool full = __logf(V) + log_invalpha - __logf(a * rus * rus + b) <= -lam + kf * loglam - log_factorial(kf);
+                acc = acc || (cand && full);
+            }
+            if (!done && acc) { result = kf; done = true; }
+        }
+        if (!__any(!done)) break;
     }
-    return floorf(lam + 0.5f);
+    return result;
 }
 
-__device__ inline float gaussian(PixelRng& g) {
-    const float u1 = g.next(), u2 = g.next();
-    return __builtin_amdgcn_sqrtf(-2.f * __logf(u1)) * __cosf(6.283185307179586f * u2);
+// standard normals of a quad's read-out draw: slots (0, 1) and (2, 3) are the cos / sin branches of one Box-Muller pair each
+__device__ inline void quad_normals(const uint32_t (&o)[4], float (&n)[4]) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float r = __builtin_amdgcn_sqrtf(-2.f * __logf(u01(o[2 * h])));
+        const float t = u01(o[2 * h + 1]);                        // v_sin / v_cos take revolutions
+        n[2 * h] = r * __builtin_amdgcn_cosf(t);
+        n[2 * h + 1] = r * __builtin_amdgcn_sinf(t);
+    }
 }
 
-// photons in -> camera counts out
-__device__ inline float detector_pixel(float photons, const DetectorCfg& d, uint32_t pixel, uint32_t env) {
-    PixelRng g(pixel, env + d.env_offset, d.frame_counter, d.seed_lo, d.seed_hi);
-    float f = photons;
-    if (d.photon_noise) f = poisson(f, g);
+// everything after the photon count: QE, dark shot noise, saturation, gain, read-out noise, ADC.  `dark` = the pixel's dark
+// electrons (already drawn), `normal` = its standard normal.
+__device__ inline float detector_finish(float f, const DetectorCfg& d, float dark, float normal) {
     f *= d.qe;
-    if (d.dark_e > 0.f) f += poisson(d.dark_e, g);
+    f += dark;
     if (d.fwc > 0.f) f = fminf(fmaxf(f, 0.f), d.fwc);
     if (d.emccd) f *= d.gain;
-    if (d.readout_noise != 0.f) f += rintf(gaussian(g) * d.readout_noise);
+    if (d.readout_noise != 0.f) f += rintf(normal * d.readout_noise);
     if (!d.emccd) f *= d.gain;
     if (d.bits > 0) {
         const float top = (float)((1u << d.bits) - 1u);
@@ -127,6 +149,57 @@ __device__ inline float detector_pixel(float photons, const DetectorCfg& d, uint
         f = fminf(f, top);                                        // clip(frame, frame.min(), 2^bits - 1)
     }
     return f;
+}
+
+// One quad of the camera, photons in -> counts out (used where the caller has no cheaper arrangement: k_detector, the unlit
+// lenslets of the fused step kernel).  pix[s]: frame index of the quad's slot-s pixel (the per-pixel stream of a bright pixel).
+__device__ inline void detector_quad(float (&v)[4], const uint32_t (&pix)[4], uint32_t quad, uint32_t env, const DetectorCfg& d, float rtab) {
+    if (d.photon_noise) {
+        uint32_t o[4];
+        quad_bits(quad, env, d, kDrawPhoton, o);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float lam = v[s];
+            const bool faint = !(lam >= kPtrsFrom);
+            float k = 0.f;
+            if (__any(faint && lam > 0.f)) k = poisson_inversion(faint ? fmaxf(lam, 0.f) : 0.f, u01(o[s]), rtab);
+            if (__any(!faint)) {
+                const float kb = poisson_ptrs(faint ? kPtrsFrom : lam, pix[s], env, d);
+                k = faint ? k : kb;
+            }
+            v[s] = k;
+        }
+    }
+    float dark[4] = {0.f, 0.f, 0.f, 0.f}, nrm[4] = {0.f, 0.f, 0.f, 0.f};
+    if (d.dark_e > 0.f) {
+        uint32_t o[4];
+        quad_bits(quad, env, d, kDrawDark, o);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            dark[s] = d.dark_e < kPtrsFrom ? poisson_inversion(d.dark_e, u01(o[s]), rtab) : poisson_ptrs(d.dark_e, pix[s] | 0x80000000u, env, d);
+    }
+    if (d.readout_noise != 0.f) {
+        uint32_t o[4];
+        quad_bits(quad, env, d, kDrawReadout, o);
+        quad_normals(o, nrm);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) v[s] = detector_finish(v[s], d, dark[s], nrm[s]);
+}
+
+// Quad geometry of a Shack-Hartmann frame with 6-pixel lenslets: quad j = 0..8 of a lenslet whose top-left pixel is (y0, x0).
+//   j < 6 : column j, rows 0..3            j >= 6 : rows 4, 5 of the columns c = j - 6 (slots 0, 1) and c + 3 (slots 2, 3)
+__device__ inline void sh6_quad_pixels(int j, int y0, int x0, int cam, uint32_t (&pix)[4]) {
+    if (j < 6) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) pix[s] = (uint32_t)((y0 + s) * cam + x0 + j);
+    } else {
+        const int c = j - 6;
+        pix[0] = (uint32_t)((y0 + 4) * cam + x0 + c);
+        pix[1] = (uint32_t)((y0 + 5) * cam + x0 + c);
+        pix[2] = (uint32_t)((y0 + 4) * cam + x0 + c + 3);
+        pix[3] = (uint32_t)((y0 + 5) * cam + x0 + c + 3);
+    }
 }
 
 // host-side launcher (detector_kernels.hip): applies the camera to frame [E][cam*cam] in place; for a Shack-Hartmann

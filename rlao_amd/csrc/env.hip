@@ -49,8 +49,24 @@ struct AoEnv {
     // device memory (element type = dtype unless noted)
     void* screen[1] = {nullptr};            // [L][E][S*S], every screen a torus (see atm_kernels.hip)
     void* minmax = nullptr;                 // [L][E][2]
-    uint32_t* mt_state = nullptr;           // [L][E][624]
-    int* mt_pos = nullptr;                  // [L][E]
+    uint32_t* mt_state = nullptr;           // [2][L][E][624]: per layer one committed copy and one the ring look-ahead writes
+    int* mt_pos = nullptr;                  // [2][L][E]
+    uint32_t* mt_cur[kMaxLayer] = {nullptr};   // committed MT19937 state of every layer's ring stream ...
+    int* pos_cur[kMaxLayer] = {nullptr};
+    uint32_t* mt_alt[kMaxLayer] = {nullptr};   // ... and the other copy (swapped in when a look-ahead is consumed)
+    int* pos_alt[kMaxLayer] = {nullptr};
+    // Ring look-ahead (float32 fused path): the extrusion X = A Z + B xi of a layer's NEXT pixel crossing does not depend on the
+    // steps in between (the screen only changes at crossings, the stream position too), so it is computed right after the
+    // previous crossing on a second stream and the crossing step only waits for an event: k_ring_prepare + the ring GEMM
+    // (19 us, on a third of the steps) leave the critical path.
+    struct RingAhead { bool valid = false; int sx = 0, sy = 0, splits = 0; hipEvent_t ready = nullptr; };
+    RingAhead ahead[kMaxLayer];
+    hipStream_t side = nullptr;             // the look-ahead's stream
+    hipEvent_t ev_main = nullptr;           // "the step kernel that wrote the last ring is done" (recorded on the caller's stream)
+    void* zx_ahead = nullptr;               // [L][E][K]
+    void* xbuf_ahead = nullptr;             // [L][splits][E][nout]
+    const void* ring_src[kMaxLayer] = {nullptr};   // slabs of the pending (deferred) ring of every layer: xbuf or xbuf_ahead
+    bool use_lookahead = true;              // aoenv_set_option(AOENV_OPT_RING_LOOKAHEAD)
     void* zx = nullptr;                     // [E][K]  [Z | xi]
     void* xbuf = nullptr;                   // [splits][E][nout] split-K slabs of the ring GEMM
     void* ab = nullptr;                     // [nout][K]
@@ -132,6 +148,8 @@ struct AoEnv {
     }
     void* minmax_ptr(int l) const { return static_cast<char*>(minmax) + (size_t)l * E * 2 * esz; }
     void* xbuf_ptr(int l) const { return static_cast<char*>(xbuf) + (size_t)l * kMaxSplits * E * nout * esz; }
+    void* xbuf_ahead_ptr(int l) const { return static_cast<char*>(xbuf_ahead) + (size_t)l * kMaxSplits * E * nout * esz; }
+    void* zx_ahead_ptr(int l) const { return static_cast<char*>(zx_ahead) + (size_t)l * E * K * esz; }
 };
 
 namespace {
@@ -240,7 +258,7 @@ template <typename T>
 int flush_ring(AoEnv* env, int l, hipStream_t st) {
     if (!env->ring_pending[l]) return 0;
     AO_PROF(env, SCATTER, st);
-    AO_TRY(launch_scatter_minmax<T>(env->as<T>(env->screen_ptr(0, l)), env->as<T>(env->xbuf_ptr(l)), env->outer_idx,
+    AO_TRY(launch_scatter_minmax<T>(env->as<T>(env->screen_ptr(0, l)), static_cast<const T*>(env->ring_src[l]), env->outer_idx,
                                     env->as<T>(env->minmax_ptr(l)), env->E, env->S, env->nout, env->ring_pending[l],
                                     env->org[l][0], env->org[l][1], 0, st));
     env->ring_pending[l] = 0;
@@ -252,10 +270,32 @@ int flush_rings(AoEnv* env, hipStream_t st) {
     return 0;
 }
 
+// Host-synchronous invalidation of every look-ahead (the screens, the streams or the operators are about to be replaced from the host)
+int sync_lookaheads(AoEnv* env) {
+    if (!env->side) return 0;
+    AO_HIP(hipStreamSynchronize(env->side));
+    for (int l = 0; l < env->L; ++l) env->ahead[l].valid = false;
+    return 0;
+}
+
+// A look-ahead that will not be used (its inputs changed): nothing of it was committed -- the stream copy it advanced is the
+// alternate one, its slabs are scratch -- but the caller's stream must not reuse those buffers before it has finished.
+int drop_lookahead(AoEnv* env, int l, hipStream_t st) {
+    if (!env->ahead[l].valid) return 0;
+    env->ahead[l].valid = false;
+    AO_HIP(hipStreamWaitEvent(st, env->ahead[l].ready, 0));
+    return 0;
+}
+int drop_lookaheads(AoEnv* env, hipStream_t st) {
+    for (int l = 0; l < env->L; ++l) AO_TRY(drop_lookahead(env, l, st));
+    return 0;
+}
+
 // lean: no min / max pass (the fused step kernel recomputes the range from the map);  defer: not even the scatter -- the
 // fused step kernel of this step writes the ring itself (one launch less per crossing)
 template <typename T>
 int extrude(AoEnv* env, int l, int sx, int sy, bool lean, hipStream_t st, bool defer = false) {
+    AO_TRY(drop_lookahead(env, l, st));                            // computed from the screen and the stream as they were
     AO_TRY(flush_ring<T>(env, l, st));                             // an earlier extrusion of this layer in the same step
     T* map = env->as<T>(env->screen_ptr(0, l));
     T* zx = env->as<T>(env->zx);
@@ -263,9 +303,8 @@ int extrude(AoEnv* env, int l, int sx, int sy, bool lean, hipStream_t st, bool d
     const int oy = env->org[l][0], ox = env->org[l][1];
     {
         AO_PROF(env, SHIFT_GATHER, st);                           // Z gather + xi draw, one launch
-        AO_TRY(launch_ring_prepare<T>(map, zx, env->inner_idx, env->mt_state + (size_t)l * env->E * kMtN,
-                                      env->mt_pos + (size_t)l * env->E, env->E, S, env->nin, env->nout, env->K, sx, sy, oy, ox,
-                                      st));
+        AO_TRY(launch_ring_prepare<T>(map, zx, env->inner_idx, env->mt_cur[l], env->pos_cur[l], env->mt_cur[l], env->pos_cur[l], env->E, S,
+                                      env->nin, env->nout, env->K, sx, sy, oy, ox, st));
     }
     int splits = 1;
     {
@@ -278,6 +317,7 @@ int extrude(AoEnv* env, int l, int sx, int sy, bool lean, hipStream_t st, bool d
     env->org[l][1] = ((ox - sx) % S + S) % S;
     if (defer && lean) {
         env->ring_pending[l] = splits;
+        env->ring_src[l] = env->xbuf_ptr(l);
     } else {
         AO_PROF(env, SCATTER, st);
         AO_TRY(launch_scatter_minmax<T>(map, env->as<T>(env->xbuf_ptr(l)), env->outer_idx, env->as<T>(env->minmax_ptr(l)), env->E, S,
@@ -315,7 +355,22 @@ int advance_atmosphere(AoEnv* env, bool lean, hipStream_t st) {
         if (std::fabs(k.buff[0]) >= 1 || std::fabs(k.buff[1]) >= 1) {
             const int b0 = std::fabs(k.buff[0]) < 1 ? 0 : (int)sgn(k.buff[0]);
             const int b1 = std::fabs(k.buff[1]) < 1 ? 0 : (int)sgn(k.buff[1]);
-            AO_TRY(extrude<T>(env, l, b0, b1, lean, st, lean && env->defer_ring));
+            AoEnv::RingAhead& ah = env->ahead[l];
+            if (lean && env->defer_ring && ah.valid && ah.sx == b0 && ah.sy == b1 && !env->ring_pending[l]) {
+                // the extrusion of this crossing was computed ahead: wait for it, commit its stream copy, move the torus origin
+                AO_HIP(hipStreamWaitEvent(st, ah.ready, 0));
+                ah.valid = false;
+                std::swap(env->mt_cur[l], env->mt_alt[l]);
+                std::swap(env->pos_cur[l], env->pos_alt[l]);
+                const int S = env->S;
+                env->org[l][0] = ((env->org[l][0] - b1) % S + S) % S;
+                env->org[l][1] = ((env->org[l][1] - b0) % S + S) % S;
+                env->ring_pending[l] = ah.splits;
+                env->ring_src[l] = env->xbuf_ahead_ptr(l);
+                env->minmax_dirty[l] = true;
+            } else {
+                AO_TRY(extrude<T>(env, l, b0, b1, lean, st, lean && env->defer_ring));
+            }
         }
         for (int d = 0; d < 2; ++d) k.buff[d] = std::fmod(std::fabs(k.buff[d]), 1.0) * sgn(k.buff[d]);
     }
@@ -546,6 +601,60 @@ void fill_phase_args(AoEnv* env, PhaseArgs& pa, PhaseBuffers<T>& pb, int update_
     pb.wfs_max = env->as<T>(env->wfs_max);
 }
 
+// The direction of a layer's next sub-pixel crossing, by running its clock forward (same arithmetic as advance_atmosphere).
+static bool next_crossing(const LayerClock& k0, int* sx, int* sy) {
+    if ((int)std::fabs(k0.ratio[0]) > 0 || (int)std::fabs(k0.ratio[1]) > 0) return false;   // whole-pixel shifts every step: no look-ahead
+    if (k0.ratio[0] == 0 && k0.ratio[1] == 0) return false;
+    double b[2] = {k0.buff[0], k0.buff[1]};
+    for (int it = 0; it < 1000000; ++it) {
+        for (int d = 0; d < 2; ++d) b[d] += std::fmod(std::fabs(k0.ratio[d]), 1.0) * sgn(k0.ratio[d]);
+        if (std::fabs(b[0]) >= 1 || std::fabs(b[1]) >= 1) {
+            *sx = std::fabs(b[0]) < 1 ? 0 : (int)sgn(b[0]);
+            *sy = std::fabs(b[1]) < 1 ? 0 : (int)sgn(b[1]);
+            return true;
+        }
+        for (int d = 0; d < 2; ++d) b[d] = std::fmod(std::fabs(b[d]), 1.0) * sgn(b[d]);
+    }
+    return false;
+}
+
+// After a fused step: for every layer without one, compute the ring extrusion of its next crossing on the side stream.  It reads
+// the screen as this step's kernel leaves it (ring of this step included) and the committed stream copy, and writes the slabs
+// X = [A | B] [Z; xi] and the advanced stream to buffers of its own; the crossing step commits them (advance_atmosphere).
+static int launch_lookaheads(AoEnv* env, hipStream_t st) {
+    if (!env->use_lookahead || !env->side || !env->defer_ring) return 0;
+    bool recorded = false;
+    for (int l = 0; l < env->L; ++l) {
+        AoEnv::RingAhead& ah = env->ahead[l];
+        int sx = 0, sy = 0;
+        if (ah.valid || !next_crossing(env->clk[l], &sx, &sy)) continue;
+        if (!recorded) {
+            AO_HIP(hipEventRecord(env->ev_main, st));
+            AO_HIP(hipStreamWaitEvent(env->side, env->ev_main, 0));
+            recorded = true;
+        }
+        float* zx = static_cast<float*>(env->zx_ahead_ptr(l));
+        {
+            AO_PROF(env, SHIFT_GATHER, env->side);
+            AO_TRY(launch_ring_prepare<float>(env->as<float>(env->screen_ptr(0, l)), zx, env->inner_idx, env->mt_cur[l], env->pos_cur[l],
+                                              env->mt_alt[l], env->pos_alt[l], env->E, env->S, env->nin, env->nout, env->K, sx, sy,
+                                              env->org[l][0], env->org[l][1], env->side));
+        }
+        int splits = 1;
+        {
+            AO_PROF(env, GEMM_RING, env->side);
+            AO_TRY(gemm_dispatch<float>(env, zx, env->as<float>(env->ab), static_cast<float*>(env->xbuf_ahead_ptr(l)), env->E, env->nout,
+                                        env->K, &splits, env->side));
+        }
+        AO_HIP(hipEventRecord(ah.ready, env->side));
+        ah.valid = true;
+        ah.sx = sx;
+        ah.sy = sy;
+        ah.splits = splits;
+    }
+    return 0;
+}
+
 template <typename T>
 int run_fused_step(AoEnv*, int, const void*, void*, void*, void*, double, hipStream_t) { return fail("fused step: float32 only"); }
 template <>
@@ -581,7 +690,7 @@ int run_fused_step<float>(AoEnv* env, int i, const void* d_action, void* d_obs, 
     if (env->det.active) env->det.frame_counter += 1;              // every measurement is a new frame of the noise streams
     a.det = env->det;
     for (int l = 0; l < env->L; ++l) {
-        a.ring_x[l] = env->ring_pending[l] ? env->as<float>(env->xbuf_ptr(l)) : nullptr;
+        a.ring_x[l] = env->ring_pending[l] ? static_cast<const float*>(env->ring_src[l]) : nullptr;
         a.ring_splits[l] = env->ring_pending[l];
     }
     a.outer_idx = env->outer_idx;
@@ -596,7 +705,7 @@ int run_fused_step<float>(AoEnv* env, int i, const void* d_action, void* d_obs, 
     }
     for (int l = 0; l < env->L; ++l) env->minmax_dirty[l] = false;   // the kernel recomputed and stored them
     for (int l = 0; l < env->L; ++l) env->ring_pending[l] = 0;        // ... and wrote the deferred rings
-    return 0;
+    return launch_lookaheads(env, st);
 }
 
 template <typename T>
@@ -750,8 +859,12 @@ int aoenv_create(const AoCfg* cfg, int device, AoEnv** out) {
     if (e->L > 0) {
         A_(&e->screen[0], (size_t)e->L * E * e->S * e->S * z);
         A_(&e->minmax, (size_t)e->L * E * 2 * z);
-        A_((void**)&e->mt_state, (size_t)e->L * E * kMtN * 4);
-        A_((void**)&e->mt_pos, (size_t)e->L * E * 4);
+        A_((void**)&e->mt_state, (size_t)2 * e->L * E * kMtN * 4);
+        A_((void**)&e->mt_pos, (size_t)2 * e->L * E * 4);
+        if (cfg->dtype == AOENV_F32) {                              // ring look-ahead (fused float32 path)
+            A_(&e->zx_ahead, (size_t)e->L * E * e->K * z);
+            A_(&e->xbuf_ahead, (size_t)e->L * kMaxSplits * E * e->nout * z);
+        }
         A_(&e->zx, E * e->K * z);
         A_(&e->xbuf, (size_t)e->L * kMaxSplits * E * e->nout * z);
         A_(&e->ab, (size_t)e->nout * e->K * z);
@@ -805,6 +918,18 @@ int aoenv_create(const AoCfg* cfg, int device, AoEnv** out) {
     }
     A_(&e->vbuf, (size_t)kMaxSplits * E * e->A * z);
     if (rc) { aoenv_destroy(e); return rc; }
+    for (int l = 0; l < e->L; ++l) {
+        e->mt_cur[l] = e->mt_state + (size_t)l * E * kMtN;
+        e->mt_alt[l] = e->mt_state + (size_t)(e->L + l) * E * kMtN;
+        e->pos_cur[l] = e->mt_pos + (size_t)l * E;
+        e->pos_alt[l] = e->mt_pos + (size_t)(e->L + l) * E;
+    }
+    if (e->zx_ahead) {
+        bool ok = hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) == hipSuccess &&
+                  hipEventCreateWithFlags(&e->ev_main, hipEventDisableTiming) == hipSuccess;
+        for (int l = 0; l < e->L && ok; ++l) ok = hipEventCreateWithFlags(&e->ahead[l].ready, hipEventDisableTiming) == hipSuccess;
+        if (!ok) { aoenv_destroy(e); return fail("could not create the look-ahead stream / events"); }
+    }
 
     // DFT twiddles w^k = exp(-2 pi i k / n) and the centring phasor exp(-i pi (n+1)/n x) at x = a + lo
     // (OOPAO/ShackHartmann.py:208-209), in float64 then converted
@@ -837,6 +962,10 @@ int aoenv_create(const AoCfg* cfg, int device, AoEnv** out) {
 int aoenv_destroy(AoEnv* env) {
     if (!env) return 0;
     DeviceGuard ao_device_guard(env->device);
+    if (env->side) { (void)hipStreamSynchronize(env->side); (void)hipStreamDestroy(env->side); }
+    if (env->ev_main) (void)hipEventDestroy(env->ev_main);
+    for (int l = 0; l < kMaxLayer; ++l)
+        if (env->ahead[l].ready) (void)hipEventDestroy(env->ahead[l].ready);
     for (auto& e : env->prof_ev) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (void* p : env->allocs) (void)hipFree(p);
     delete env;
@@ -863,6 +992,7 @@ int aoenv_upload(AoEnv* env, int kind, const void* h, size_t bytes) {
         case AOENV_C_AB:
             if (env->L == 0) return fail("no atmosphere in this shard");
             AO_TRY(need((size_t)env->nout * env->K * 8));
+            AO_TRY(sync_lookaheads(env));                          // a ring computed ahead used the old operators
             AO_TRY(upload_real(env, env->ab, d, (size_t)env->nout * env->K));
             break;
         case AOENV_C_INNER_IDX:
@@ -1028,12 +1158,14 @@ static int require_step_constants(AoEnv* env, bool atmosphere) {
 static int finish_new_screens(AoEnv* env, const uint32_t* h_ring_seeds, hipStream_t st) {
     const int E = env->E, L = env->L;
     for (int l = 0; l < L; ++l) env->ring_pending[l] = 0;          // a deferred ring of the old screens is moot
-    std::vector<uint32_t> keys((size_t)L * E * kMtN);
-    std::vector<int> pos((size_t)L * E, kMtN);
-    for (int l = 0; l < L; ++l)
-        for (int e = 0; e < E; ++e) mt_seed(h_ring_seeds[(size_t)e * L + l], &keys[((size_t)l * E + e) * kMtN]);
-    AO_HIP(hipMemcpy(env->mt_state, keys.data(), keys.size() * 4, hipMemcpyHostToDevice));
-    AO_HIP(hipMemcpy(env->mt_pos, pos.data(), pos.size() * 4, hipMemcpyHostToDevice));
+    AO_TRY(sync_lookaheads(env));
+    std::vector<uint32_t> keys((size_t)E * kMtN);
+    std::vector<int> pos((size_t)E, kMtN);
+    for (int l = 0; l < L; ++l) {
+        for (int e = 0; e < E; ++e) mt_seed(h_ring_seeds[(size_t)e * L + l], &keys[(size_t)e * kMtN]);
+        AO_HIP(hipMemcpy(env->mt_cur[l], keys.data(), keys.size() * 4, hipMemcpyHostToDevice));
+        AO_HIP(hipMemcpy(env->pos_cur[l], pos.data(), pos.size() * 4, hipMemcpyHostToDevice));
+    }
     for (int l = 0; l < L; ++l) {
         env->clk[l].buff[0] = env->clk[l].buff[1] = 0;            // notDoneOnce (OOPAO/Atmosphere.py:586, 359-364)
         AO_TRY(AO_DISPATCH(env, extrude, env, l, 0, 0, false, st));   // (the callers reset the torus origin with the new interior)
@@ -1316,7 +1448,7 @@ int aoenv_set_detector(AoEnv* env, const AoDetector* cfg, void* stream) {
         if (!d.photon_noise && d.bits == 0 && d.qe == 1.f && d.dark_e == 0.f && d.fwc == 0.f && d.gain == 1.f && d.readout_noise == 0.f)
             d.active = 0;
     }
-    if (env->det.active && !d.active)                              // no stale noise outside the valid lenslets
+    if (env->det.active)                                           // no stale noise outside the valid lenslets (the new camera may not write there)
         AO_HIP(hipMemsetAsync(env->frame, 0, (size_t)env->E * env->c.cam_res * env->c.cam_res * env->esz, st));
     if (!cfg) {                                                    // ideal detector: the stream position and its seed are kept
         d.seed_lo = env->det.seed_lo; d.seed_hi = env->det.seed_hi; d.frame_counter = env->det.frame_counter;
@@ -1377,9 +1509,9 @@ int aoenv_download(AoEnv* env, int which, void* h_dst, size_t bytes, void* strea
         const size_t n = (size_t)env->L * env->E;
         std::vector<uint32_t> st_(n * kMtN);
         std::vector<int> pos(n);
-        if (n) {
-            AO_HIP(hipMemcpy(st_.data(), env->mt_state, st_.size() * 4, hipMemcpyDeviceToHost));
-            AO_HIP(hipMemcpy(pos.data(), env->mt_pos, pos.size() * 4, hipMemcpyDeviceToHost));
+        for (int l = 0; l < env->L; ++l) {                         // the committed copy of every layer (a look-ahead writes the other)
+            AO_HIP(hipMemcpy(&st_[(size_t)l * env->E * kMtN], env->mt_cur[l], (size_t)env->E * kMtN * 4, hipMemcpyDeviceToHost));
+            AO_HIP(hipMemcpy(&pos[(size_t)l * env->E], env->pos_cur[l], (size_t)env->E * 4, hipMemcpyDeviceToHost));
         }
         uint32_t* out = static_cast<uint32_t*>(h_dst);
         for (size_t i = 0; i < n; ++i) {
@@ -1412,6 +1544,7 @@ int aoenv_upload_state(AoEnv* env, int which, const void* h_src, size_t bytes, v
     AO_HIP(hipStreamSynchronize(st));
     if (which == AOENV_B_SCREEN) {
         // logical layer.mapShift of every env: the tori restart at origin 0; the clip range is re-derived by its next consumer
+        AO_TRY(sync_lookaheads(env));
         for (int l = 0; l < env->L; ++l) {
             const size_t per = (size_t)env->E * env->S * env->S * env->esz;
             AO_HIP(hipMemcpy(env->screen_ptr(0, l), static_cast<const char*>(h_src) + l * per, per, hipMemcpyHostToDevice));
@@ -1432,9 +1565,10 @@ int aoenv_upload_state(AoEnv* env, int which, const void* h_src, size_t bytes, v
             pos[i] = (int)in[i * (kMtN + 1) + kMtN];
             if (pos[i] < 0 || pos[i] > kMtN || pos[i] % 4) return fail("MT19937 position %d is not a multiple of 4 in [0, 624]", pos[i]);
         }
-        if (n) {
-            AO_HIP(hipMemcpy(env->mt_state, st_.data(), st_.size() * 4, hipMemcpyHostToDevice));
-            AO_HIP(hipMemcpy(env->mt_pos, pos.data(), pos.size() * 4, hipMemcpyHostToDevice));
+        AO_TRY(sync_lookaheads(env));
+        for (int l = 0; l < env->L; ++l) {
+            AO_HIP(hipMemcpy(env->mt_cur[l], &st_[(size_t)l * env->E * kMtN], (size_t)env->E * kMtN * 4, hipMemcpyHostToDevice));
+            AO_HIP(hipMemcpy(env->pos_cur[l], &pos[(size_t)l * env->E], (size_t)env->E * 4, hipMemcpyHostToDevice));
         }
         return 0;
     }
@@ -1473,6 +1607,10 @@ int aoenv_set_option(AoEnv* env, int option, int value) {
         case AOENV_OPT_FUSED_STEP: env->use_fused_step = value != 0; return 0;
         case AOENV_OPT_DEFER_RING: env->defer_ring = value != 0; return 0;
         case AOENV_OPT_FACTORED_RECON: env->use_factored_recon = value != 0; return 0;
+        case AOENV_OPT_RING_LOOKAHEAD:
+            if (!value) AO_TRY(sync_lookaheads(env));
+            env->use_lookahead = value != 0;
+            return 0;
         case AOENV_OPT_COEFS_IMAGE:
             if (value) AO_TRY(alloc_dm_rows(env));
             env->use_coefs_img = value != 0;

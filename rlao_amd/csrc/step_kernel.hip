@@ -99,6 +99,8 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
     __shared__ double red[4][16];
     __shared__ double red_tail[16];
     __shared__ float red_mx[16];
+    __shared__ int q_count_s;                                    // bright pixels queued for the rejection sampler (stage B camera)
+    int* q_count = &q_count_s;
 
     const int e = blockIdx.x;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
@@ -140,6 +142,7 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
     for (int i = tid; i < 2 * PR * SS; i += 1024) s1[i] = 0.f;
     if (tid < n_sub * n_sub) slot_s[tid] = slot_v;
     for (int i = tid + 1024; i < n_sub * n_sub; i += 1024) slot_s[i] = a.slot_of[i];
+    if (tid == 0) q_count_s = 0;
     lds_barrier();
     if (has_act) cimg[act_px] = act_c;
     // the integrator's input of this lane's actuator (previous observation, or the caller's action): needed only in stage C
@@ -454,16 +457,105 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
         const int kk = a.sc.subap_idx[s];
         li = kk / n_sub;
         lj = kk - li * n_sub;
-        if (a.det.active) {                                      // self*self.cam: the camera on the lane's 12 pixels
-            const uint32_t q0 = (uint32_t)((li * 6) * R + lj * 6 + q3);
-#pragma unroll 1
-            for (int u = 0; u < 6; ++u) {
-                const float va = detector_pixel(Ia[u], a.det, q0 + (uint32_t)(u * R), (uint32_t)e);
-                const float vb = detector_pixel(Ib[u], a.det, q0 + (uint32_t)(u * R) + 3u, (uint32_t)e);
-                Ia[u] = va;
-                Ib[u] = vb;
+    }
+    if (a.det.active) {
+        // ---- self*self.cam: the camera on the lane's 12 pixels (detector.hpp, "Stream layout") --------------------------------
+        // pixel p of the lane: p < 6 is (row p, column q3) = Ia[p], p >= 6 is (row p - 6, column q3 + 3) = Ib[p - 6]; its three
+        // quads: t = 0 rows 0..3 of column q3, t = 1 rows 0..3 of column q3 + 3, t = 2 rows 4, 5 of both columns.
+        // Faint pixels (lambda < 10) are drawn here by inversion, every lane walking its 12 pixels; the bright ones (a few per
+        // lenslet, ~1/5 of the frame) go through a queue in LDS and are drawn by ALL lanes of the workgroup, densely packed: as a
+        // per-lane branch the rejection sampler ran for the 12 pixels of every lane, in as many rounds as the slowest lane needed.
+        const float rtab = recip_table_lane();
+        const uint32_t px0 = (uint32_t)((li * 6) * R + lj * 6 + q3);           // frame index of the lane's pixel (row 0, column q3)
+        const uint32_t quad_id[3] = {px0, px0 + 3u, px0 + (uint32_t)(4 * R)};
+        auto pix_of = [&](int p) { return px0 + (uint32_t)((p < 6 ? p : p - 6) * R + (p < 6 ? 0 : 3)); };
+        float2* queue = reinterpret_cast<float2*>(lds + L.mapt);              // {lambda -> count, frame pixel}; the layer tiles are dead
+        const int q_cap = (16 * WR * WC) / 2;
+        uint32_t bright = 0;
+        int q_base = 0;
+        if (a.det.photon_noise) {
+            uint32_t qb[3][4];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) quad_bits(quad_id[t], (uint32_t)e, a.det, kDrawPhoton, qb[t]);
+#pragma unroll
+            for (int p = 0; p < 12; ++p) {
+                const int row = p < 6 ? p : p - 6, t = row < 4 ? (p < 6 ? 0 : 1) : 2, slot = row < 4 ? row : (row - 4) + (p < 6 ? 0 : 2);
+                float& v = p < 6 ? Ia[row] : Ib[row];
+                const bool faint = !ok || !(v >= kPtrsFrom);
+                const float lam = faint && ok ? fmaxf(v, 0.f) : 0.f;
+                float kf = 0.f;
+                if (__any(lam > 0.f)) kf = poisson_inversion(lam, u01(qb[t][slot]), rtab);
+                if (faint) v = kf; else bright |= 1u << p;
+            }
+            const int nb = __popc(bright);
+            if (nb) q_base = atomicAdd(q_count, nb);
+            if (q_base + nb > q_cap) {                                        // queue full (a very bright star): this lane's own work
+#pragma unroll
+                for (int p = 0; p < 12; ++p)
+                    if (bright >> p & 1u) {
+                        float& v = p < 6 ? Ia[p] : Ib[p - 6];
+                        v = poisson_ptrs(v, pix_of(p), (uint32_t)e, a.det);
+                    }
+                bright = 0;
+            } else {
+                int r = q_base;
+#pragma unroll
+                for (int p = 0; p < 12; ++p)
+                    if (bright >> p & 1u) {
+                        queue[r] = make_float2(p < 6 ? Ia[p] : Ib[p - 6], __uint_as_float(pix_of(p)));
+                        ++r;
+                    }
+            }
+            lds_barrier();
+            const int n_q = min(*q_count, q_cap);
+            for (int i0 = 64 * w; i0 < n_q; i0 += 1024) {                      // whole waves: the sampler votes across the wave
+                const int i = i0 + lane;
+                const float2 it = queue[i < n_q ? i : 0];
+                const float kf = poisson_ptrs(i < n_q ? it.x : kPtrsFrom, __float_as_uint(it.y), (uint32_t)e, a.det);
+                if (i < n_q) queue[i].x = kf;
+            }
+            lds_barrier();
+            {
+                int r = q_base;
+#pragma unroll
+                for (int p = 0; p < 12; ++p)
+                    if (bright >> p & 1u) {
+                        (p < 6 ? Ia[p] : Ib[p - 6]) = queue[r].x;
+                        ++r;
+                    }
             }
         }
+        // QE, dark shot noise, saturation, gain, read-out noise, ADC: quad by quad
+        const bool has_dark = a.det.dark_e > 0.f, has_read = a.det.readout_noise != 0.f;
+        if (has_dark || has_read || a.det.qe != 1.f || a.det.gain != 1.f || a.det.fwc > 0.f || a.det.bits > 0) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                float dark[4] = {0.f, 0.f, 0.f, 0.f}, nrm[4] = {0.f, 0.f, 0.f, 0.f};
+                if (has_dark) {
+                    uint32_t o[4];
+                    quad_bits(quad_id[t], (uint32_t)e, a.det, kDrawDark, o);
+#pragma unroll
+                    for (int sl4 = 0; sl4 < 4; ++sl4) {
+                        const int p = t == 0 ? sl4 : (t == 1 ? 6 + sl4 : (sl4 < 2 ? 4 + sl4 : 8 + sl4));
+                        dark[sl4] = a.det.dark_e < kPtrsFrom ? poisson_inversion(a.det.dark_e, u01(o[sl4]), rtab)
+                                                             : poisson_ptrs(a.det.dark_e, pix_of(p) | 0x80000000u, (uint32_t)e, a.det);
+                    }
+                }
+                if (has_read) {
+                    uint32_t o[4];
+                    quad_bits(quad_id[t], (uint32_t)e, a.det, kDrawReadout, o);
+                    quad_normals(o, nrm);
+                }
+#pragma unroll
+                for (int sl4 = 0; sl4 < 4; ++sl4) {
+                    // slot -> the lane's pixel: t = 0: rows 0..3 of Ia; t = 1: rows 0..3 of Ib; t = 2: Ia[4], Ia[5], Ib[4], Ib[5]
+                    float& v = t == 0 ? Ia[sl4] : (t == 1 ? Ib[sl4] : (sl4 < 2 ? Ia[4 + sl4] : Ib[2 + sl4]));
+                    v = detector_finish(v, a.det, dark[sl4], nrm[sl4]);
+                }
+            }
+        }
+    }
+    if (ok) {
         float* fr = a.frame + pix0 + (size_t)(li * 6) * R + lj * 6 + q3;
 #pragma unroll
         for (int u = 0; u < 6; ++u) {
@@ -474,14 +566,19 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
         }
     }
     AO_STAMP(15);
-    if (a.det.active) {
+    if (a.det.active && (a.det.dark_e > 0.f || a.det.readout_noise != 0.f)) {
         // the camera also reads out the pixels of the lenslets that are not valid (no light): dark + read-out noise, ADC
-        for (int idx = tid; idx < n_sub * n_sub * 36; idx += 1024) {
-            const int kk = idx / 36, pp = idx - 36 * kk;
+        const float rtab = recip_table_lane();
+        for (int idx = tid; idx < n_sub * n_sub * 9; idx += 1024) {
+            const int kk = idx / 9, j = idx - 9 * kk;
             if (slot_s[kk] < 0) {
                 const int i2 = kk / n_sub, j2 = kk - i2 * n_sub;
-                const uint32_t q = (uint32_t)((i2 * 6 + pp / 6) * R + j2 * 6 + pp % 6);
-                a.frame[pix0 + q] = detector_pixel(0.f, a.det, q, (uint32_t)e);
+                uint32_t pix[4];
+                sh6_quad_pixels(j, i2 * 6, j2 * 6, R, pix);
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+                detector_quad(v, pix, pix[0], (uint32_t)e, a.det, rtab);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) a.frame[pix0 + pix[s4]] = v[s4];
             }
         }
     }

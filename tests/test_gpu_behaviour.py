@@ -35,7 +35,7 @@ def test_switches_agree_small():
     from rlao_amd import _lib as L
     from rlao_amd.env import BatchedAOEnv
     ref = None
-    for opts in [dict(), {L.OPT_DEFER_RING: 0}, {L.OPT_FUSED_STEP: 0}, {L.OPT_FUSED_STEP: 0, L.OPT_COEFS_IMAGE: 1},
+    for opts in [dict(), {L.OPT_RING_LOOKAHEAD: 0}, {L.OPT_DEFER_RING: 0}, {L.OPT_FUSED_STEP: 0}, {L.OPT_FUSED_STEP: 0, L.OPT_COEFS_IMAGE: 1},
                  {L.OPT_FUSED_STEP: 0, L.OPT_COEFS_IMAGE: 1, L.OPT_MFMA_GEMM: 0}, {L.OPT_FUSED_STEP: 0, L.OPT_FAST_TRIG: 0}, {L.OPT_FAST_WFS: 0}, {L.OPT_MFMA_GEMM: 0}, {L.OPT_FAST_TRIG: 0}, {L.OPT_FUSED_TAIL: 0},
                  {L.OPT_FUSED_TAIL: 0, L.OPT_MFMA_GEMM: 0},
                  {L.OPT_FUSED_TAIL: 0, L.OPT_FACTORED_RECON: 0}, {L.OPT_FUSED_TAIL: 0, L.OPT_FACTORED_RECON: 0, L.OPT_MFMA_GEMM: 0},
@@ -49,6 +49,10 @@ def test_switches_agree_small():
         if ref is None:
             ref = out
             continue
+        if opts == {L.OPT_RING_LOOKAHEAD: 0}:                 # the ring computed ahead on the side stream IS the ring computed in place
+            import torch
+            for x, y in zip(out, ref):
+                assert all(torch.equal(p, q) for p, q in zip(x, y))
         for (o, f, r, s), (o0, f0, r0, s0) in zip(out, ref):
             np.testing.assert_allclose(o.cpu().numpy(), o0.cpu().numpy(), atol=2e-5)
             np.testing.assert_allclose(f.cpu().numpy(), f0.cpu().numpy(), atol=2e-5 * float(f0.max()))
