@@ -51,6 +51,11 @@ __device__ inline void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_
 
 __device__ inline float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }   // (0, 1)
 
+// (4-vectors indexed by a loop counter are ext_vector registers: the compiler indexes those with v_movrel, while a float[4] --
+//  even behind a select chain -- is turned into an indexed array in scratch memory)
+typedef float f32x4d __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4d __attribute__((ext_vector_type(4)));
+
 constexpr float kPtrsFrom = 10.f;                              // PTRS is valid from lambda = 10 (NumPy switches there too)
 enum { kDrawPhoton = 0, kDrawDark = 1, kDrawReadout = 2, kDrawPixelStream = 16 };
 
@@ -124,7 +129,7 @@ __device__ inline float poisson_ptrs(float lam, uint32_t pixel, uint32_t env, co
 }
 
 // standard normals of a quad's read-out draw: slots (0, 1) and (2, 3) are the cos / sin branches of one Box-Muller pair each
-__device__ inline void quad_normals(const uint32_t (&o)[4], float (&n)[4]) {
+__device__ inline void quad_normals(const uint32_t (&o)[4], f32x4d& n) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const float r = __builtin_amdgcn_sqrtf(-2.f * __logf(u01(o[2 * h])));
@@ -151,32 +156,47 @@ __device__ inline float detector_finish(float f, const DetectorCfg& d, float dar
     return f;
 }
 
+// word `s` of a quad's draw / element `s` of a 4-vector with a run-time (wave-uniform) s: selects, not an indexed array
+// (which would live in scratch memory); the slot loops below are NOT unrolled -- one copy of each sampler keeps the kernels that
+// inline this small enough for the instruction cache (12 unrolled copies made the fused step kernel 114 KB of code)
+__device__ inline uint32_t word_of(const uint32_t (&o)[4], int s) {
+    const u32x4d ov = {o[0], o[1], o[2], o[3]};
+    return ov[s];
+}
+
 // One quad of the camera, photons in -> counts out (used where the caller has no cheaper arrangement: k_detector, the unlit
 // lenslets of the fused step kernel).  pix[s]: frame index of the quad's slot-s pixel (the per-pixel stream of a bright pixel).
-__device__ inline void detector_quad(float (&v)[4], const uint32_t (&pix)[4], uint32_t quad, uint32_t env, const DetectorCfg& d, float rtab) {
-    if (d.photon_noise) {
+// PHOTON = false: the quad is known to hold no light (unlit lenslets): only dark current / read-out / ADC.
+template <bool PHOTON = true>
+__device__ inline void detector_quad(f32x4d& v, const uint32_t (&pix)[4], uint32_t quad, uint32_t env, const DetectorCfg& d, float rtab) {
+    const u32x4d pv = {pix[0], pix[1], pix[2], pix[3]};
+    if (PHOTON && d.photon_noise) {
         uint32_t o[4];
         quad_bits(quad, env, d, kDrawPhoton, o);
-#pragma unroll
+#pragma unroll 1
         for (int s = 0; s < 4; ++s) {
             const float lam = v[s];
             const bool faint = !(lam >= kPtrsFrom);
             float k = 0.f;
-            if (__any(faint && lam > 0.f)) k = poisson_inversion(faint ? fmaxf(lam, 0.f) : 0.f, u01(o[s]), rtab);
+            if (__any(faint && lam > 0.f)) k = poisson_inversion(faint ? fmaxf(lam, 0.f) : 0.f, u01(word_of(o, s)), rtab);
             if (__any(!faint)) {
-                const float kb = poisson_ptrs(faint ? kPtrsFrom : lam, pix[s], env, d);
+                const uint32_t px = pv[s];
+                const float kb = poisson_ptrs(faint ? kPtrsFrom : lam, px, env, d);
                 k = faint ? k : kb;
             }
             v[s] = k;
         }
     }
-    float dark[4] = {0.f, 0.f, 0.f, 0.f}, nrm[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4d dark = {0.f, 0.f, 0.f, 0.f}, nrm = {0.f, 0.f, 0.f, 0.f};
     if (d.dark_e > 0.f) {
         uint32_t o[4];
         quad_bits(quad, env, d, kDrawDark, o);
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-            dark[s] = d.dark_e < kPtrsFrom ? poisson_inversion(d.dark_e, u01(o[s]), rtab) : poisson_ptrs(d.dark_e, pix[s] | 0x80000000u, env, d);
+#pragma unroll 1
+        for (int s = 0; s < 4; ++s) {
+            const uint32_t px = pv[s];
+            dark[s] = d.dark_e < kPtrsFrom ? poisson_inversion(d.dark_e, u01(word_of(o, s)), rtab)
+                                           : poisson_ptrs(d.dark_e, px | 0x80000000u, env, d);
+        }
     }
     if (d.readout_noise != 0.f) {
         uint32_t o[4];

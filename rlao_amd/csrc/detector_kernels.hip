@@ -41,10 +41,10 @@ __global__ void __launch_bounds__(256) k_detector(T* __restrict__ frame, T* __re
                 lit = valid2d[(r / p) * n_subap + c4 / p] != 0;  // (a quad never straddles lenslets it matters for: p % 4 == 0 or sh6)
             }
         }
-        float v[4];
+        f32x4d v;
 #pragma unroll
         for (int s = 0; s < 4; ++s) v[s] = in[s] ? (float)fr[pix[s]] : 0.f;
-        detector_quad(v, pix, pix[0], (uint32_t)e, d, rtab);
+        detector_quad<true>(v, pix, pix[0], (uint32_t)e, d, rtab);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             if (in[s]) fr[pix[s]] = (T)v[s];

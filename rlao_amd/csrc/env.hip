@@ -66,7 +66,7 @@ struct AoEnv {
     void* zx_ahead = nullptr;               // [L][E][K]
     void* xbuf_ahead = nullptr;             // [L][splits][E][nout]
     const void* ring_src[kMaxLayer] = {nullptr};   // slabs of the pending (deferred) ring of every layer: xbuf or xbuf_ahead
-    bool use_lookahead = true;              // aoenv_set_option(AOENV_OPT_RING_LOOKAHEAD)
+    bool use_lookahead = false;             // aoenv_set_option(AOENV_OPT_RING_LOOKAHEAD): off by default, see aoenv.h
     void* zx = nullptr;                     // [E][K]  [Z | xi]
     void* xbuf = nullptr;                   // [splits][E][nout] split-K slabs of the ring GEMM
     void* ab = nullptr;                     // [nout][K]
@@ -555,6 +555,7 @@ template <>
 bool fused_step_ok<float>(const AoEnv* env) {
     return env->use_fused_step && env->use_fast_wfs && env->use_mfma && env->use_fused_tail && env->c.wfs_type == AOENV_WFS_SH && env->c.dm_separable && env->n_modes > 0 &&
            env->c.max_group == 1 && env->L > 0 && env->c.cam_res == env->R && env->debug_ablate == 0 &&
+           !(env->det.active && env->det.dark_e >= 10.f) &&      // (the fused camera draws the dark electrons by inversion only)
            step_fused_supported(env->R, env->nSub, env->nVal, env->nAct, env->n_modes) != 0;
 }
 

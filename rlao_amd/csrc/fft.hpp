@@ -213,6 +213,113 @@ __device__ inline void fft_stage_any(cx<T>* __restrict__ src, cx<T>* __restrict_
     }
 }
 
+// ---- compile-time plans ----------------------------------------------------------------------------------------------------
+// The same stages with the transform length N, the stage's ns and the direction as template parameters: every division and
+// modulo of the index arithmetic is by a constant, the twiddle strides fold, and the conjugation for the inverse is free.  The
+// Pyramid's lengths (288 = 16.2.3.3 and 528 = 16.3.11: BASELINE configs[2] and the reference's Papyrus set-up) take this path;
+// with run-time plans the index arithmetic was 2/3 of the instructions of the column pass.
+template <typename T, bool INV>
+__device__ inline cx<T> tw_ct(const cx<T>* __restrict__ twl, int k) {
+    cx<T> w = twl[k];
+    if (INV) w.im = -w.im;
+    return w;
+}
+
+template <typename T, int R, int N, int NS, bool INV>
+__device__ inline void fft_stage_ct(const cx<T>* __restrict__ src, cx<T>* __restrict__ dst, int nseq, const cx<T>* __restrict__ twl) {
+    constexpr int m = N / R, tstep = m / NS, np = (N - 1 + ((N - 1) >> 4) + 1) | 1, H = (R - 1) / 2;
+    constexpr bool prime = (R == 3 || R == 5 || R == 7 || R == 11 || R == 13);
+    T C[prime ? R : 1], S[prime ? R : 1];
+    if constexpr (prime) {
+#pragma unroll
+        for (int p2 = 1; p2 < R; ++p2) {
+            const cx<T> wv = tw_ct<T, INV>(twl, p2 * m);
+            C[p2] = wv.re;
+            S[p2] = wv.im;
+        }
+    }
+    for (int w = threadIdx.x; w < nseq * m; w += blockDim.x) {
+        const int seq = w / m, j = w - seq * m;
+        const int jd = j / NS, k = j - jd * NS;
+        const cx<T>* s = src + seq * np;
+        cx<T> v[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            v[r] = s[fpad(j + r * m)];
+            if (r > 0 && NS > 1) v[r] = cmul(v[r], tw_ct<T, INV>(twl, k * r * tstep));
+        }
+        cx<T>* d = dst + seq * np;
+        const int o = jd * NS * R + k;
+        if constexpr (R == 16) {
+            cx<T> y[R];
+            dft16<T>(v, y, INV ? 1 : 0);
+#pragma unroll
+            for (int q = 0; q < R; ++q) d[fpad(o + q * NS)] = y[q];
+        } else if constexpr (R == 2) {
+            d[fpad(o)] = cadd(v[0], v[1]);
+            d[fpad(o + NS)] = csub(v[0], v[1]);
+        } else if constexpr (R == 4) {
+            dft4<T>(v[0], v[1], v[2], v[3], INV ? 1 : 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) d[fpad(o + q * NS)] = v[q];
+        } else {
+            static_assert(prime, "radix without a compile-time stage");
+            cx<T> a[H + 1], b[H + 1];
+            cx<T> y0 = v[0];
+#pragma unroll
+            for (int r = 1; r <= H; ++r) {
+                a[r] = cadd(v[r], v[R - r]);
+                b[r] = csub(v[r], v[R - r]);
+                y0 = cadd(y0, a[r]);
+            }
+            d[fpad(o)] = y0;
+#pragma unroll
+            for (int q = 1; q <= H; ++q) {
+                T cr = v[0].re, ci = v[0].im, sr = 0, si = 0;
+#pragma unroll
+                for (int r = 1; r <= H; ++r) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int p2 = (q * r) % R;
+                    cr += a[r].re * C[p2];
+                    ci += a[r].im * C[p2];
+                    sr += b[r].re * S[p2];
+                    si += b[r].im * S[p2];
+                }
+                d[fpad(o + q * NS)] = {cr - si, ci + sr};
+                d[fpad(o + (R - q) * NS)] = {cr + si, ci - sr};
+            }
+        }
+    }
+}
+
+// 288 = 16 . 2 . 3 . 3   and   528 = 16 . 3 . 11 (the radix order of make_fft_plan); returns the buffer holding the result
+template <typename T, int N, bool INV>
+__device__ inline cx<T>* fft_lds_ct(cx<T>* a, cx<T>* b, int nseq, const cx<T>* __restrict__ twl) {
+    static_assert(N == 288 || N == 528, "no compile-time plan for this length");
+    __syncthreads();
+    fft_stage_ct<T, 16, N, 1, INV>(a, b, nseq, twl);
+    __syncthreads();
+    if constexpr (N == 528) {
+        fft_stage_ct<T, 3, N, 16, INV>(b, a, nseq, twl);
+        __syncthreads();
+        fft_stage_ct<T, 11, N, 48, INV>(a, b, nseq, twl);
+        __syncthreads();
+        return b;
+    } else {
+        fft_stage_ct<T, 2, N, 16, INV>(b, a, nseq, twl);
+        __syncthreads();
+        fft_stage_ct<T, 3, N, 32, INV>(a, b, nseq, twl);
+        __syncthreads();
+        fft_stage_ct<T, 3, N, 96, INV>(b, a, nseq, twl);
+        __syncthreads();
+        return a;
+    }
+}
+
+// run-time plan, or the compile-time one when NFIX = plan length
+template <typename T, int NFIX>
+__device__ inline cx<T>* fft_any(cx<T>* a, cx<T>* b, const FftPlan& pl, int nseq, const cx<T>* __restrict__ twl, int inverse);
+
 // Full 1-D transform of `nseq` sequences; returns the buffer that holds the result (a or b).  twl: the n-entry twiddle
 // table in LDS (fft_load_twiddles; the first stage's barrier orders it).
 template <typename T>
@@ -241,6 +348,15 @@ __device__ inline cx<T>* fft_lds(cx<T>* a, cx<T>* b, const FftPlan& pl, int nseq
     }
     __syncthreads();
     return src;
+}
+
+template <typename T, int NFIX>
+__device__ inline cx<T>* fft_any(cx<T>* a, cx<T>* b, const FftPlan& pl, int nseq, const cx<T>* __restrict__ twl, int inverse) {
+    if constexpr (NFIX == 0) {
+        return fft_lds<T>(a, b, pl, nseq, twl, inverse);
+    } else {
+        return inverse ? fft_lds_ct<T, NFIX, true>(a, b, nseq, twl) : fft_lds_ct<T, NFIX, false>(a, b, nseq, twl);
+    }
 }
 
 }  // namespace ao

@@ -24,7 +24,7 @@ namespace ao {
 constexpr size_t kFftLdsTarget = 40 * 1024;
 
 // P1: grid = (ceil(R / RB), chunk, E)
-template <typename T>
+template <typename T, int NFIX>
 __global__ void __launch_bounds__(256) k_pyr_rows(const PyrArgs<T> a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int N = a.N, NP = a.plan.np, R = a.R, RB = a.seq_per_block;
@@ -70,14 +70,14 @@ __global__ void __launch_bounds__(256) k_pyr_rows(const PyrArgs<T> a) {
         }
         A[r * NP + fpad(xg)] = v;
     }
-    cx<T>* out = fft_lds<T>(A, B, a.plan, RB, twl, 0);
+    cx<T>* out = fft_any<T, NFIX>(A, B, a.plan, RB, twl, 0);
     cx<T>* t1 = a.t1 + (((size_t)e * a.n_theta_chunk + th) * R + y0) * N;
     for (int r = 0; r < nrow; ++r)
         for (int x = threadIdx.x; x < N; x += blockDim.x) t1[(size_t)r * N + x] = out[r * NP + fpad(x)];
 }
 
 // P2: grid = (N / CB, chunk, E); CB columns per workgroup
-template <typename T>
+template <typename T, int NFIX>
 __global__ void __launch_bounds__(256) k_pyr_cols(const PyrArgs<T> a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int N = a.N, NP = a.plan.np, R = a.R, CB = a.seq_per_block;
@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(256) k_pyr_cols(const PyrArgs<T> a) {
             if (i0 + u * (int)blockDim.x < R * CB)
                 A[cc[u] * NP + fpad(a.off + yy[u])] = v[u];          // (odd sequence stride NP: the CB lanes hit CB banks)
     }
-    cx<T>* f = fft_lds<T>(A, B, a.plan, CB, twl, 0);
+    cx<T>* f = fft_any<T, NFIX>(A, B, a.plan, CB, twl, 0);
     cx<T>* g = (f == A) ? B : A;
     // focal plane: [fftshift] + mask   (Pyramid.py:486-497).  Shifted position i holds frequency (i + N/2) mod N.
     const int h = a.centering ? 0 : N / 2;
@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(256) k_pyr_cols(const PyrArgs<T> a) {
             g[c * NP + fpad(ky)] = cmul(v, cx<T>{mk[0], mk[1]});
         }
     }
-    cx<T>* r = fft_lds<T>(g, f, a.plan, CB, twl, 1);
+    cx<T>* r = fft_any<T, NFIX>(g, f, a.plan, CB, twl, 1);
     cx<T>* t2 = a.t2 + ((size_t)e * a.n_theta_chunk + th) * N * N;
     const int jx0 = (kx0 + h) % N;                                // CB divides N/2: the block's columns stay contiguous
     for (int i = threadIdx.x; i < N * CB; i += blockDim.x) {
@@ -187,13 +187,13 @@ int launch_psf(const PyrArgs<T>& base, T* psf, hipStream_t st) {
     if (cb < 2 || (N / 2) % cb || (N / 2) % 2) return fail("psf: N = %d has no even column block", N);
     const size_t lds1 = (size_t)(2 * rb * NP + N) * sizeof(cx<T>), lds2 = (size_t)(2 * cb * NP + N) * sizeof(cx<T>);
     if (lds1 > 64 * 1024)
-        AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyr_rows<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+        AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyr_rows<T, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
     if (lds2 > 64 * 1024)
         AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_psf_cols<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     a.theta0 = 0;
     a.n_theta_chunk = 1;
     a.seq_per_block = rb;
-    hipLaunchKernelGGL(k_pyr_rows<T>, dim3(cdiv(R, rb), 1, a.n_env), dim3(256), lds1, st, a);
+    hipLaunchKernelGGL((k_pyr_rows<T, 0>), dim3(cdiv(R, rb), 1, a.n_env), dim3(256), lds1, st, a);
     a.seq_per_block = cb;
     a.magic_seq = (unsigned)((1ull << 32) / (unsigned)cb) + 1u;
     hipLaunchKernelGGL(k_psf_cols<T>, dim3(N / cb, 1, a.n_env), dim3(256), lds2, st, a, psf);
@@ -204,7 +204,7 @@ template int launch_psf<float>(const PyrArgs<float>&, float*, hipStream_t);
 template int launch_psf<double>(const PyrArgs<double>&, double*, hipStream_t);
 
 // P3: grid = (cam, E); the nb = N / cam rows of one camera row, all modulation points of the chunk
-template <typename T>
+template <typename T, int NFIX>
 __global__ void __launch_bounds__(256) k_pyr_rows_inv(const PyrArgs<T> a, int accumulate) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     // the nb rows of a camera row go through LDS in sub-batches of SB = seq_per_block rows (two buffers of SB sequences:
@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(256) k_pyr_rows_inv(const PyrArgs<T> a, int ac
             for (int q = 0; q < SB; ++q)
                 for (int x = threadIdx.x; x < N; x += blockDim.x)
                     A[q * NP + fpad(x)] = q < ns ? t2[(size_t)(q0 + q) * N + x] : cx<T>{0, 0};
-            cx<T>* r = fft_lds<T>(A, B, a.plan, SB, twl, 1);
+            cx<T>* r = fft_any<T, NFIX>(A, B, a.plan, SB, twl, 1);
             for (int x = threadIdx.x; x < N; x += blockDim.x) {
                 T s = 0;
                 for (int q = 0; q < ns; ++q) {
@@ -282,8 +282,8 @@ __global__ void __launch_bounds__(256) k_pyr_slopes(const PyrSlopeArgs<T> a) {
     }
 }
 
-template <typename T>
-int launch_pyramid(const PyrArgs<T>& base, int n_theta, int chunk, hipStream_t st) {
+template <typename T, int NFIX>
+int launch_pyramid_n(const PyrArgs<T>& base, int n_theta, int chunk, hipStream_t st) {
     PyrArgs<T> a = base;
     const int N = a.N, R = a.R;
     // sequences per workgroup: keep the two LDS buffers within 64 KiB (P3 may need more: raised explicitly)
@@ -301,26 +301,34 @@ int launch_pyramid(const PyrArgs<T>& base, int n_theta, int chunk, hipStream_t s
     const size_t lds3 = (size_t)(2 * sb * NP + N) * sizeof(cx<T>) + (size_t)N * sizeof(T);
     const size_t lds1 = (size_t)(2 * rb * NP + N) * sizeof(cx<T>), lds2 = (size_t)(2 * cb * NP + N) * sizeof(cx<T>);
     if (lds1 > 64 * 1024)
-        AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyr_rows<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+        AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyr_rows<T, NFIX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
     if (lds2 > 64 * 1024)
-        AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyr_cols<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyr_cols<T, NFIX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     if (lds3 > 160 * 1024) return fail("pyramid: %d rows of nRes = %d per camera row do not fit in LDS", nb, N);
     if (lds3 > 64 * 1024)
-        AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyr_rows_inv<T>),
+        AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyr_rows_inv<T, NFIX>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
     for (int t0 = 0; t0 < n_theta; t0 += chunk) {
         a.theta0 = t0;
         a.n_theta_chunk = (n_theta - t0) < chunk ? (n_theta - t0) : chunk;
         a.seq_per_block = rb;
-        hipLaunchKernelGGL(k_pyr_rows<T>, dim3(cdiv(R, rb), a.n_theta_chunk, a.n_env), dim3(256), lds1, st, a);
+        hipLaunchKernelGGL((k_pyr_rows<T, NFIX>), dim3(cdiv(R, rb), a.n_theta_chunk, a.n_env), dim3(256), lds1, st, a);
         a.seq_per_block = cb;
         a.magic_seq = (unsigned)((1ull << 32) / (unsigned)cb) + 1u;
-        hipLaunchKernelGGL(k_pyr_cols<T>, dim3(cdiv(N / cb, 8) * 8, a.n_theta_chunk, a.n_env), dim3(256), lds2, st, a);
+        hipLaunchKernelGGL((k_pyr_cols<T, NFIX>), dim3(cdiv(N / cb, 8) * 8, a.n_theta_chunk, a.n_env), dim3(256), lds2, st, a);
         a.seq_per_block = sb;
-        hipLaunchKernelGGL(k_pyr_rows_inv<T>, dim3(a.cam, a.n_env), dim3(256), lds3, st, a, t0 > 0 ? 1 : 0);
+        hipLaunchKernelGGL((k_pyr_rows_inv<T, NFIX>), dim3(a.cam, a.n_env), dim3(256), lds3, st, a, t0 > 0 ? 1 : 0);
         AO_HIP(hipGetLastError());
     }
     return 0;
+}
+
+// the float32 transforms of the two lengths the reference's configurations use have compile-time plans (fft.hpp)
+template <typename T>
+int launch_pyramid(const PyrArgs<T>& base, int n_theta, int chunk, hipStream_t st) {
+    if (sizeof(T) == 4 && base.N == 528 && base.plan.n_fac == 3) return launch_pyramid_n<T, 528>(base, n_theta, chunk, st);
+    if (sizeof(T) == 4 && base.N == 288 && base.plan.n_fac == 4) return launch_pyramid_n<T, 288>(base, n_theta, chunk, st);
+    return launch_pyramid_n<T, 0>(base, n_theta, chunk, st);
 }
 
 template <typename T>

@@ -458,6 +458,7 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
         li = kk / n_sub;
         lj = kk - li * n_sub;
     }
+    AO_STAMP(22);
     if (a.det.active) {
         // ---- self*self.cam: the camera on the lane's 12 pixels (detector.hpp, "Stream layout") --------------------------------
         // pixel p of the lane: p < 6 is (row p, column q3) = Ia[p], p >= 6 is (row p - 6, column q3 + 3) = Ib[p - 6]; its three
@@ -465,47 +466,56 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
         // Faint pixels (lambda < 10) are drawn here by inversion, every lane walking its 12 pixels; the bright ones (a few per
         // lenslet, ~1/5 of the frame) go through a queue in LDS and are drawn by ALL lanes of the workgroup, densely packed: as a
         // per-lane branch the rejection sampler ran for the 12 pixels of every lane, in as many rounds as the slowest lane needed.
+        // The pixel loops are rolled (one copy of each sampler; the registers are picked by select chains on the loop index).
         const float rtab = recip_table_lane();
         const uint32_t px0 = (uint32_t)((li * 6) * R + lj * 6 + q3);           // frame index of the lane's pixel (row 0, column q3)
-        const uint32_t quad_id[3] = {px0, px0 + 3u, px0 + (uint32_t)(4 * R)};
         auto pix_of = [&](int p) { return px0 + (uint32_t)((p < 6 ? p : p - 6) * R + (p < 6 ? 0 : 3)); };
+        auto pixel_of_slot = [](int t, int sl4) { return t == 0 ? sl4 : (t == 1 ? 6 + sl4 : (sl4 < 2 ? 4 + sl4 : 8 + sl4)); };
+        // the lane's 12 pixels as ONE vector register group indexed by the (wave-uniform) loop counter: v_movrel-class register
+        // indexing.  (float[6] arrays picked by select chains were turned back into an indexed array in scratch memory.)
+        typedef float f32x16s __attribute__((ext_vector_type(16)));
+        f32x16s pxv;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { pxv[i] = Ia[i]; pxv[6 + i] = Ib[i]; }
+#pragma unroll
+        for (int i = 12; i < 16; ++i) pxv[i] = 0.f;
+        auto pick = [&](int p) { return pxv[p]; };
+        auto put = [&](int p, float v) { pxv[p] = v; };
         float2* queue = reinterpret_cast<float2*>(lds + L.mapt);              // {lambda -> count, frame pixel}; the layer tiles are dead
         const int q_cap = (16 * WR * WC) / 2;
         uint32_t bright = 0;
         int q_base = 0;
         if (a.det.photon_noise) {
-            uint32_t qb[3][4];
-#pragma unroll
-            for (int t = 0; t < 3; ++t) quad_bits(quad_id[t], (uint32_t)e, a.det, kDrawPhoton, qb[t]);
-#pragma unroll
-            for (int p = 0; p < 12; ++p) {
-                const int row = p < 6 ? p : p - 6, t = row < 4 ? (p < 6 ? 0 : 1) : 2, slot = row < 4 ? row : (row - 4) + (p < 6 ? 0 : 2);
-                float& v = p < 6 ? Ia[row] : Ib[row];
-                const bool faint = !ok || !(v >= kPtrsFrom);
-                const float lam = faint && ok ? fmaxf(v, 0.f) : 0.f;
-                float kf = 0.f;
-                if (__any(lam > 0.f)) kf = poisson_inversion(lam, u01(qb[t][slot]), rtab);
-                if (faint) v = kf; else bright |= 1u << p;
+#pragma unroll 1
+            for (int t = 0; t < 3; ++t) {
+                uint32_t o[4];
+                quad_bits(px0 + (t == 1 ? 3u : (t == 2 ? (uint32_t)(4 * R) : 0u)), (uint32_t)e, a.det, kDrawPhoton, o);
+#pragma unroll 1
+                for (int sl4 = 0; sl4 < 4; ++sl4) {
+                    const int p = pixel_of_slot(t, sl4);
+                    const float v = pick(p);
+                    const bool faint = !ok || !(v >= kPtrsFrom);
+                    const float lam = faint && ok ? fmaxf(v, 0.f) : 0.f;
+                    float kf = 0.f;
+                    if (__any(lam > 0.f)) kf = poisson_inversion(lam, u01(word_of(o, sl4)), rtab);
+                    if (faint) put(p, kf);
+                    bright |= faint ? 0u : 1u << p;
+                }
             }
             const int nb = __popc(bright);
             if (nb) q_base = atomicAdd(q_count, nb);
             if (q_base + nb > q_cap) {                                        // queue full (a very bright star): this lane's own work
-#pragma unroll
+#pragma unroll 1
                 for (int p = 0; p < 12; ++p)
-                    if (bright >> p & 1u) {
-                        float& v = p < 6 ? Ia[p] : Ib[p - 6];
-                        v = poisson_ptrs(v, pix_of(p), (uint32_t)e, a.det);
-                    }
+                    if (bright >> p & 1u) put(p, poisson_ptrs(pick(p), pix_of(p), (uint32_t)e, a.det));
                 bright = 0;
             } else {
                 int r = q_base;
-#pragma unroll
+#pragma unroll 1
                 for (int p = 0; p < 12; ++p)
-                    if (bright >> p & 1u) {
-                        queue[r] = make_float2(p < 6 ? Ia[p] : Ib[p - 6], __uint_as_float(pix_of(p)));
-                        ++r;
-                    }
+                    if (bright >> p & 1u) queue[r++] = make_float2(pick(p), __uint_as_float(pix_of(p)));
             }
+            AO_STAMP(23);
             lds_barrier();
             const int n_q = min(*q_count, q_cap);
             for (int i0 = 64 * w; i0 < n_q; i0 += 1024) {                      // whole waves: the sampler votes across the wave
@@ -514,46 +524,42 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
                 const float kf = poisson_ptrs(i < n_q ? it.x : kPtrsFrom, __float_as_uint(it.y), (uint32_t)e, a.det);
                 if (i < n_q) queue[i].x = kf;
             }
+            AO_STAMP(2);
             lds_barrier();
             {
                 int r = q_base;
-#pragma unroll
+#pragma unroll 1
                 for (int p = 0; p < 12; ++p)
-                    if (bright >> p & 1u) {
-                        (p < 6 ? Ia[p] : Ib[p - 6]) = queue[r].x;
-                        ++r;
-                    }
+                    if (bright >> p & 1u) put(p, queue[r++].x);
             }
         }
-        // QE, dark shot noise, saturation, gain, read-out noise, ADC: quad by quad
+        // QE, dark shot noise, saturation, gain, read-out noise, ADC: quad by quad (dark_e < kPtrsFrom: checked by the host)
         const bool has_dark = a.det.dark_e > 0.f, has_read = a.det.readout_noise != 0.f;
         if (has_dark || has_read || a.det.qe != 1.f || a.det.gain != 1.f || a.det.fwc > 0.f || a.det.bits > 0) {
-#pragma unroll
+#pragma unroll 1
             for (int t = 0; t < 3; ++t) {
-                float dark[4] = {0.f, 0.f, 0.f, 0.f}, nrm[4] = {0.f, 0.f, 0.f, 0.f};
+                const uint32_t qid = px0 + (t == 1 ? 3u : (t == 2 ? (uint32_t)(4 * R) : 0u));
+                f32x4d dark = {0.f, 0.f, 0.f, 0.f}, nrm = {0.f, 0.f, 0.f, 0.f};
                 if (has_dark) {
                     uint32_t o[4];
-                    quad_bits(quad_id[t], (uint32_t)e, a.det, kDrawDark, o);
-#pragma unroll
-                    for (int sl4 = 0; sl4 < 4; ++sl4) {
-                        const int p = t == 0 ? sl4 : (t == 1 ? 6 + sl4 : (sl4 < 2 ? 4 + sl4 : 8 + sl4));
-                        dark[sl4] = a.det.dark_e < kPtrsFrom ? poisson_inversion(a.det.dark_e, u01(o[sl4]), rtab)
-                                                             : poisson_ptrs(a.det.dark_e, pix_of(p) | 0x80000000u, (uint32_t)e, a.det);
-                    }
+                    quad_bits(qid, (uint32_t)e, a.det, kDrawDark, o);
+#pragma unroll 1
+                    for (int sl4 = 0; sl4 < 4; ++sl4) dark[sl4] = poisson_inversion(a.det.dark_e, u01(word_of(o, sl4)), rtab);
                 }
                 if (has_read) {
                     uint32_t o[4];
-                    quad_bits(quad_id[t], (uint32_t)e, a.det, kDrawReadout, o);
+                    quad_bits(qid, (uint32_t)e, a.det, kDrawReadout, o);
                     quad_normals(o, nrm);
                 }
-#pragma unroll
+#pragma unroll 1
                 for (int sl4 = 0; sl4 < 4; ++sl4) {
-                    // slot -> the lane's pixel: t = 0: rows 0..3 of Ia; t = 1: rows 0..3 of Ib; t = 2: Ia[4], Ia[5], Ib[4], Ib[5]
-                    float& v = t == 0 ? Ia[sl4] : (t == 1 ? Ib[sl4] : (sl4 < 2 ? Ia[4 + sl4] : Ib[2 + sl4]));
-                    v = detector_finish(v, a.det, dark[sl4], nrm[sl4]);
+                    const int p = pixel_of_slot(t, sl4);
+                    put(p, detector_finish(pick(p), a.det, dark[sl4], nrm[sl4]));
                 }
             }
         }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { Ia[i] = pxv[i]; Ib[i] = pxv[6 + i]; }
     }
     if (ok) {
         float* fr = a.frame + pix0 + (size_t)(li * 6) * R + lj * 6 + q3;
@@ -575,8 +581,8 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
                 const int i2 = kk / n_sub, j2 = kk - i2 * n_sub;
                 uint32_t pix[4];
                 sh6_quad_pixels(j, i2 * 6, j2 * 6, R, pix);
-                float v[4] = {0.f, 0.f, 0.f, 0.f};
-                detector_quad(v, pix, pix[0], (uint32_t)e, a.det, rtab);
+                f32x4d v = {0.f, 0.f, 0.f, 0.f};
+                detector_quad<false>(v, pix, pix[0], (uint32_t)e, a.det, rtab);
 #pragma unroll
                 for (int s4 = 0; s4 < 4; ++s4) a.frame[pix0 + pix[s4]] = v[s4];
             }

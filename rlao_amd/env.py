@@ -815,6 +815,23 @@ class BatchedAOEnv:
             raise ValueError(f"dm_prev must be 0 or have shape ({self.nValidAct},) or ({self.n_envs}, {self.nValidAct})")
         self._shard.upload_state(L.B_DM_PREV, v, self._stream())
 
+    def render4plot(self, current_i):
+        """MAIN/OOPAOEnv/OOPAOEnv.py:473-482: short-exposure PSF of the current residual (``tel.computePSF(4)``) and the
+        long-exposure one, ``LE_PSF = mean(log10(PSF))`` over the frames with ``current_i > 15`` -- a running sum on the device
+        instead of the reference's growing list.  Returns (LE_PSF, log10(PSF)); leading env dimension unless n_envs == 1."""
+        torch = _torch()
+        self.tel.computePSF(4)
+        se = torch.log10(torch.as_tensor(self.tel.PSF, device=self.device)) if self.output == "numpy" else torch.log10(self.tel.PSF)
+        if current_i > 15:
+            self._se_sum = se.clone() if getattr(self, "_se_sum", None) is None else self._se_sum + se
+            self._se_n = getattr(self, "_se_n", 0) + 1
+            self.LE_PSF = self._se_sum / self._se_n
+            if self.output == "numpy":
+                self.LE_PSF = self.LE_PSF.double().cpu().numpy()
+        return self.LE_PSF, (se.double().cpu().numpy() if self.output == "numpy" else se)
+
+    render = render4plot                      # the reference's render() is render4plot() plus a matplotlib window
+
     def get_strehl(self):
         return float(self._strehl[0]) if self.n_envs == 1 else self._strehl.clone()
 

@@ -7,8 +7,10 @@ from rlao_amd.env import BatchedAOEnv
 from rlao_amd import _lib as L
 import bench
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+CAM = sys.argv[2] if len(sys.argv) > 2 else "papyrus"
 env = BatchedAOEnv(n_envs=N, device=0, dtype="f32")
-env.set_params(dict(bench.GEOMETRY, nLoop=600), wfs_type="shackhartmann")
+env.set_params(dict(bench.GEOMETRY, nLoop=600), wfs_type="shackhartmann", camera=CAM)
+print("camera:", CAM)
 env.generate_new_phase_screen(17); env.dm.coefs = 0; env.measure(); env.reset_soft()
 env.run_integrator(0, 50); torch.cuda.synchronize()
 lib = L.load()
@@ -17,9 +19,10 @@ assert lib.aoenv_debug_stamps(st.ctypes.data_as(C.c_void_p), st.shape[0]) == 0
 st = st.astype(np.int64)
 names = {0: "start", 1: "p0 sync", 3: "p0 s1 (mfma) + amp loads issued", 4: "p0 tile in LDS", 5: "p0 interp done",
          7: "p1 start(after mfma/epilogue p0)", 9: "p1 s1", 10: "p1 tile in LDS", 11: "p1 interp done",
-         13: "p1 epilogue done", 14: "E0 sync", 15: "spots+frame done", 16: "max sync", 17: "centroid sync",
+         13: "p1 epilogue done", 14: "E0 sync", 22: "spots (DFT) done", 23: "camera: faint pixels drawn, queue written",
+         2: "camera: queue drawn (wave 0)", 15: "camera finished, frame stored", 16: "max sync", 17: "centroid sync",
          19: "tail: t = M s", 20: "tail: o = M2C t, integrator", 21: "tail: obs write + reduce", 18: "tail: scalar finish"}
-idx = [0, 1, 3, 4, 5, 7, 9, 10, 11, 13, 14, 15, 16, 17, 19, 20, 21, 18]
+idx = [0, 1, 3, 4, 5, 7, 9, 10, 11, 13, 14, 22] + ([23, 2] if CAM != "ideal" else []) + [15, 16, 17, 19, 20, 21, 18]
 names[1] = "prologue + s1 (mfma)"; names[3] = "p0 amp loads issued, sync"; names[9] = "p1 amp loads issued, sync"
 prev = None
 for i in idx:
