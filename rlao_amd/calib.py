@@ -190,47 +190,6 @@ class AtmosphereTables:
         return out
 
 
-def new_phase_screen(r0: float, L0: float, n: int, delta: float, seed: int) -> np.ndarray:
-    """One N x N von Karman screen in rad @ 500 nm: FFT screen + 3 sub-harmonic grids
-    (OOPAO/phaseStats.py:190-318).  Kept quirks: both generators start from the same seed (:268, :272) and
-    only the i, j in {0, 1} corner of each 3 x 3 sub-harmonic grid is summed (:306-309)."""
-    l0 = 1e-10
-    fm = 5.92 / l0 / (2 * np.pi)
-    f0 = 1.0 / L0
-
-    def psd_of(f):
-        return 0.023 * r0 ** (-5.0 / 3) * np.exp(-1 * (f / fm) ** 2) / ((f ** 2 + f0 ** 2) ** (11.0 / 6))
-
-    rs = np.random.RandomState(seed)
-    del_f = 1.0 / (n * delta)
-    fx = np.arange(-n / 2.0, n / 2.0) * del_f
-    fx, fy = np.meshgrid(fx, fx)
-    psd = psd_of(np.sqrt(fx ** 2 + fy ** 2))
-    psd[int(n / 2), int(n / 2)] = 0
-    cn = (rs.normal(size=(n, n)) + 1j * rs.normal(size=(n, n))) * np.sqrt(psd) * del_f
-    hi = np.fft.fftshift(np.fft.fft2(np.fft.fftshift(cn))).real
-
-    rs = np.random.RandomState(seed)
-    D = n * delta
-    coords = np.arange(-n / 2, n / 2) * delta
-    x, y = np.meshgrid(coords, coords)
-    lo = np.zeros((n, n), complex)
-    for p in range(1, 4):
-        del_f = 1 / (3 ** p * D)
-        fx = np.arange(-1, 2) * del_f
-        fx, fy = np.meshgrid(fx, fx)
-        psd = psd_of(np.sqrt(fx ** 2 + fy ** 2))
-        psd[1, 1] = 0
-        cn = (rs.normal(size=(3, 3)) + 1j * rs.normal(size=(3, 3))) * np.sqrt(psd) * del_f
-        sh = np.zeros((n, n), complex)
-        for i in range(2):
-            for j in range(2):
-                sh += cn[i, j] * np.exp(1j * 2 * np.pi * (fx[i, j] * x + fy[i, j] * y))
-        lo = lo + sh
-    lo = lo.real - lo.real.mean()
-    return lo + hi
-
-
 # ------------------------------------------------------------------------------------------------------
 # Deformable mirror
 # ------------------------------------------------------------------------------------------------------

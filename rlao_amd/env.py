@@ -13,7 +13,6 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-from concurrent.futures import ThreadPoolExecutor
 from types import SimpleNamespace
 
 import numpy as np
@@ -659,11 +658,12 @@ class BatchedAOEnv:
         idx = np.arange(self.n_envs, dtype=np.int64) + self.env_index_offset
         return int(seed) + idx * self.env_seed_stride
 
-    def generate_new_phase_screen(self, seed=None, on_host=False):
+    def generate_new_phase_screen(self, seed=None, screens=None):
         """atm.generateNewPhaseScreen(seed) for every env; env e uses ``seed + e * env_seed_stride``
         (layer l: screen seed + l, ring RandomState seed + 1000 l -- OOPAO/Atmosphere.py:574-579).
-        The screens are drawn on the device (same MT19937 stream and spectrum as the reference, float64 FFT);
-        ``on_host=True`` draws them with NumPy instead and uploads them (cross-check of the device generator)."""
+        The screens are drawn on the device (same MT19937 stream and spectrum as the reference, float64 FFT).
+        ``screens`` [n_envs, nLayer, N, N] (rad @ 500 nm, N = resolution + 4): caller-made layer screens uploaded instead
+        (``aoenv_new_screens``); the rings and their RandomStates are still seeded from ``seed``."""
         import time as _t
         if seed is None:
             t = _t.localtime()
@@ -672,23 +672,14 @@ class BatchedAOEnv:
         seeds = self.env_seeds(seed)
         delta = at.layer_D / at.N
         ring = np.array([[(int(s) + 1000 * l) & 0xFFFFFFFF for l in range(p.nLayer)] for s in seeds], dtype=np.uint32)
-        if not on_host:
+        if screens is None:
             scr = np.array([[(int(s) + l) & 0xFFFFFFFF for l in range(p.nLayer)] for s in seeds], dtype=np.uint32)
             self._shard.new_screens_device(scr, ring, p.r0, p.L0, delta, self._stream())
-            self._push_wind(reset=True)
-            return
-        jobs = [(int(s), l) for s in seeds for l in range(p.nLayer)]
-
-        def make(job):
-            return calib.new_phase_screen(p.r0, p.L0, at.N, delta, job[0] + job[1])
-
-        if len(jobs) > 4:
-            with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
-                screens = list(ex.map(make, jobs))
         else:
-            screens = [make(j) for j in jobs]
-        screens = np.stack(screens).reshape(self.n_envs, p.nLayer, at.N * at.N)
-        self._shard.new_screens(screens, ring, self._stream())
+            screens = np.asarray(screens, dtype=np.float64)
+            if screens.shape != (self.n_envs, p.nLayer, at.N, at.N):
+                raise ValueError(f"screens must have shape ({self.n_envs}, {p.nLayer}, {at.N}, {at.N})")
+            self._shard.new_screens(screens.reshape(self.n_envs, p.nLayer, at.N * at.N), ring, self._stream())
         self._push_wind(reset=True)
 
     def measure(self):

@@ -103,3 +103,22 @@ def test_no_gpu_means_loud_failure(built_lib):
     bad = built_lib.AoCfg(abi_version=999)
     assert lib.aoenv_create(C.byref(bad), 0, C.byref(h)) != 0
     assert b"ABI" in lib.aoenv_last_error()
+
+
+def test_host_code_is_clean_under_asan_and_ubsan(tmp_path):
+    """the host side of libaoenv built with -fsanitize=address,undefined (`make asan`; device code as
+    usual), driven through the ABI's validation and error paths by a sanitized C driver.  No sanitizer report, exit code 0."""
+    clang = "/opt/rocm/lib/llvm/bin/clang"
+    if not os.path.exists(clang):
+        pytest.skip("no ROCm clang")
+    subprocess.run(["make", "-C", os.path.join(REPO, "rlao_amd", "csrc"), "asan", "-j4"], check=True, capture_output=True)
+    lib_dir = os.path.join(REPO, "build", "asan")
+    exe = tmp_path / "asan_driver"
+    subprocess.run([clang, "-std=c11", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", f"-I{os.path.join(REPO, 'include')}",
+                    os.path.join(REPO, "tests", "native", "asan_driver.c"), "-o", str(exe), f"-L{lib_dir}", "-laoenv_asan",
+                    f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib"], check=True, capture_output=True)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    out = subprocess.run([str(exe)], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "asan driver ok" in out.stdout
+    assert "ERROR: AddressSanitizer" not in out.stderr and "runtime error" not in out.stderr, out.stderr

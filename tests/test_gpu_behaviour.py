@@ -269,7 +269,9 @@ def test_device_phase_screens_match_oracle(dtype, n_layer):
     env.dm.coefs = 0
     env.measure()
     obs_dev = env.reset_soft().cpu().numpy()
-    env.generate_new_phase_screen(41, on_host=True)
+    host = np.stack([np.stack([O.ft_sh_phase_screen(geo["r0"], geo["L0"], N, at.layer_D / N, int(seed) + l) for l in range(n_layer)])
+                     for seed in env.env_seeds(41)])
+    env.generate_new_phase_screen(41, screens=host)           # the same screens made by the oracle on the host and uploaded
     maps_host = env._shard.download(L.B_SCREEN, (n_layer, 5, S, S))
     np.testing.assert_allclose(maps, maps_host, rtol=0, atol=tol * 10)       # the ring X = A Z + B xi amplifies 1e-12
     env.dm.coefs = 0

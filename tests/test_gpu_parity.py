@@ -16,18 +16,46 @@ CASES = ["tiny_sh", "tiny_fastwind", "tiny_3layer", "small_sh", "c2_sh", "tiny_p
 
 # Stated tolerances of the step outputs (north_star: "within a stated fp32 tolerance"), absolute unless *_rel.
 # obs is in micrometres of DM stroke (|obs| ~ 0.05-1), residual/total in nm rms (~100-2000), strehl in [0, 1],
-# signal in slope units (|s| ~ 1-10), OPD in metres (~1e-6), frame relative to its brightest pixel.
-#   float32 shards (production arithmetic): ~10x the largest error measured over the five goldens on MI355X
-#   (obs 1.7e-6, strehl 5.6e-7, rms 2.6e-4 nm, signal 5.9e-5, opd 4.2e-12 m, frame 4e-6).
-#   float64 shards: not 1e-15, because the ring-extrusion operator A = ZXt^T pinv(ZZt) is recomputed on the
-#   host of the GPU box and pinv of the ill-conditioned covariance (cond ~1e6..1e9) differs between CPUs at
-#   the 1e-9 level; everything downstream of the atmosphere inherits that.  Calibration (no atmosphere)
-#   matches the reference to 1e-13.
-F32_TOL = dict(obs=3e-5, reward_rel=1e-4, strehl=1e-5, rms_nm=3e-3, signal=6e-4, opd_m=5e-11, frame_rel=5e-5, screen=5e-4)
-F64_TOL = dict(obs=1e-6, reward_rel=1e-6, strehl=1e-6, rms_nm=1e-4, signal=5e-5, opd_m=5e-12, frame_rel=5e-6, screen=2e-5)
-#   float64 shards with the golden's OWN A, B injected (the fixtures of the R <= 48 cases hold them): the host-side pinv is out of
-#   the comparison and what is left is the device arithmetic against NumPy's -- re-ordering noise.
-F64_SAME_OPERATOR_TOL = dict(obs=1e-8, reward_rel=1e-9, strehl=1e-9, rms_nm=1e-6, signal=1e-7, opd_m=1e-15, frame_rel=1e-9, screen=1e-9)
+# signal in slope units (|s| ~ 1-10), OPD in metres (~1e-6), frame relative to its brightest pixel, screen in rad @ 500 nm.
+# Every number below is ~10x the largest error MEASURED on MI355X (AO_PARITY_REPORT=<file> dumps the maxima of a run;
+# profiles/r02_parity_maxima.json is the record these were set from).
+#   float32 shards (production arithmetic), maxima over all goldens: obs 4.2e-6, strehl 5.2e-7, rms 4.2e-4 nm, signal 5.8e-5,
+#   opd 3.5e-12 m, frame 2.7e-6, screen 5.3e-5.
+F32_TOL = dict(obs=4.5e-5, reward_rel=1e-4, strehl=6e-6, rms_nm=4.5e-3, signal=6e-4, opd_m=4e-11, frame_rel=3e-5, screen=5.5e-4)
+#   float64 shards with the golden's OWN ring operators A, B injected (the fixtures of the R <= 48 cases hold them): what is left is
+#   the device arithmetic against NumPy's -- re-ordering noise.  Measured maxima: obs 5e-14, signal 1.5e-13, strehl 2e-15,
+#   rms 1e-12 nm, opd 1e-20 m, frame 1e-14, screen 5e-14.
+F64_SAME_OPERATOR_TOL = dict(obs=1e-12, reward_rel=1e-11, strehl=1e-13, rms_nm=1e-11, signal=2e-12, opd_m=1e-18, frame_rel=1e-13, screen=1e-12)
+#   float64 shards with the operators recomputed on the test host: A = ZXt^T pinv(ZZt) goes through the pseudo-inverse of a covariance
+#   matrix of condition ~1e9 and differs between CPUs / LAPACK builds (host_A = max |A_host - A_golden| measured on the GPU box:
+#   1e-12 .. 6e-9); every ring extrusion feeds that difference into the screens and the closed loop carries it.  This -- not the
+#   device arithmetic, see above -- is what the float64 errors below are; per case, 10x measured, and scaled up if a host's
+#   operator is further from the golden's than the recorded one.
+F64_TOL_BY_CASE = {
+    "c2_sh": dict(obs=1.1e-07, signal=1.6e-05, strehl=7.0e-10, rms_nm=1.1e-06, opd_m=3.7e-13, frame_rel=3.1e-07, screen=1.2e-06, host_A=4.0e-10),
+    "c3_pyr": dict(obs=3.3e-09, signal=9.6e-07, strehl=1.0e-10, rms_nm=2.5e-08, opd_m=9.5e-14, frame_rel=5.2e-08, screen=1.9e-05, host_A=5.1e-09),
+    "c5_mcao": dict(obs=5.0e-08, signal=1.2e-06, strehl=1.0e-10, rms_nm=5.6e-08, opd_m=4.0e-14, frame_rel=4.4e-08, screen=3.2e-06, host_A=4.0e-10),
+    "papyrus_pyr": dict(obs=2.8e-06, signal=2.0e-04, strehl=1.5e-06, rms_nm=4.3e-04, opd_m=5.5e-12, frame_rel=1.6e-05, screen=3.9e-06, host_A=5.6e-09),
+    "small_sh": dict(obs=3.4e-07, signal=6.6e-06, strehl=3.4e-08, rms_nm=6.3e-05, opd_m=6.2e-13, frame_rel=5.1e-07, screen=1.5e-06, host_A=1.0e-11),
+    "tiny_3layer": dict(obs=4.9e-09, signal=7.7e-08, strehl=2.7e-09, rms_nm=1.4e-06, opd_m=1.5e-14, frame_rel=2.0e-08, screen=1.5e-07, host_A=1.7e-12),
+    "tiny_fastwind": dict(obs=4.8e-08, signal=7.4e-07, strehl=3.9e-09, rms_nm=1.1e-05, opd_m=9.8e-14, frame_rel=1.3e-07, screen=1.1e-07, host_A=1.7e-12),
+    "tiny_pyr": dict(obs=6.1e-09, signal=8.8e-07, strehl=6.4e-09, rms_nm=1.1e-06, opd_m=3.3e-14, frame_rel=5.7e-08, screen=9.9e-08, host_A=1.7e-12),
+    "tiny_pyr_mod": dict(obs=4.1e-09, signal=2.5e-07, strehl=1.2e-09, rms_nm=2.1e-07, opd_m=9.1e-15, frame_rel=9.8e-09, screen=8.0e-08, host_A=1.7e-12),
+    "tiny_sh": dict(obs=3.6e-08, signal=5.5e-07, strehl=1.4e-08, rms_nm=6.9e-06, opd_m=5.7e-14, frame_rel=1.4e-07, screen=9.9e-08, host_A=1.7e-12),
+}
+
+
+# calibration measured on the GPU in float64 (no atmosphere involved): reference slopes, interaction matrix relative to its largest
+# element.  Measured: ref 4e-13, imat 2e-14 (Pyramid nRes 528, after the field x phasor fix of round 2).
+CAL_TOL = dict(ref=1e-11, imat_rel=1e-11)
+
+
+def _f64_tol(name, host_A_now):
+    t = dict(F64_TOL_BY_CASE[name])
+    scale = max(1.0, host_A_now / t.pop("host_A"))
+    t = {k: v * scale for k, v in t.items()}
+    t["reward_rel"] = 1e-6
+    return t
 
 
 def _params(g, **kw):
@@ -150,27 +178,27 @@ def test_golden_replay(name, dtype, golden_dir):
             assert np.array_equal(env.validI4Q, g["validI4Q"])
             ref2d, valid = g["referenceSignal_2D"], g["validI4Q"]
             nv = int(valid.sum())
-            np.testing.assert_allclose(env.reference_centroids[:nv], ref2d[:ns][valid], atol=1e-9)
-            np.testing.assert_allclose(env.reference_centroids[nv:], ref2d[ns:][valid], atol=1e-9)
+            _close(env.reference_centroids[:nv], ref2d[:ns][valid], "ref", CAL_TOL, label)         # measured 4e-13 (nRes 528)
+            _close(env.reference_centroids[nv:], ref2d[ns:][valid], "ref", CAL_TOL, label)
         else:
             nv = env._sh_tables.nValid
             ref2d, valid = g["reference_slopes_maps"], g["valid_subap"]
-            np.testing.assert_allclose(env.reference_centroids[:nv], ref2d[:ns][valid], atol=1e-12)
-            np.testing.assert_allclose(env.reference_centroids[nv:], ref2d[ns:][valid], atol=1e-12)
+            _close(env.reference_centroids[:nv], ref2d[:ns][valid], "ref", CAL_TOL, label)
+            _close(env.reference_centroids[nv:], ref2d[ns:][valid], "ref", CAL_TOL, label)
             np.testing.assert_allclose(env.slopes_units, float(g["slopes_units"]), rtol=1e-9)
         if "imat" in g:
-            np.testing.assert_allclose(env.imat, g["imat"], atol=2e-9 * np.abs(g["imat"]).max())
+            _close(env.imat, g["imat"], "imat_rel", CAL_TOL, label, scale=float(np.abs(g["imat"]).max()))
             np.testing.assert_allclose(env.reconstructor, g["recon"], atol=1e-7 * np.abs(g["recon"]).max())
         else:
             # 1353 x 2608 interaction matrix: three whole columns, two random combinations of all columns, the Frobenius norm,
             # its product with the M2C and the modal command matrix built from it
-            scale = np.abs(g["imat_cols"]).max()
-            np.testing.assert_allclose(env.imat[:, g["imat_cols_idx"]], g["imat_cols"], atol=2e-9 * scale)
-            np.testing.assert_allclose(env.imat @ g["imat_probe_in"], g["imat_probe_out"], atol=2e-9 * np.abs(g["imat_probe_out"]).max())
+            scale = float(np.abs(g["imat_cols"]).max())
+            _close(env.imat[:, g["imat_cols_idx"]], g["imat_cols"], "imat_rel", CAL_TOL, label, scale=scale)
+            _close(env.imat @ g["imat_probe_in"], g["imat_probe_out"], "imat_rel", CAL_TOL, label, scale=float(np.abs(g["imat_probe_out"]).max()))
             np.testing.assert_allclose(np.linalg.norm(env.imat), float(g["imat_fro"]), rtol=1e-9)
             np.testing.assert_allclose(env.imat @ g["m2c"], g["modal_imat"], atol=2e-9 * np.abs(g["modal_imat"]).max())
             np.testing.assert_allclose(env.modal_CM, g["modal_cm"], atol=1e-7 * np.abs(g["modal_cm"]).max())
-        _replay(env, g, F64_SAME_OPERATOR_TOL if inject else (F64_TOL if dtype == "f64" else F32_TOL), seeds, label=label)
+        _replay(env, g, F64_SAME_OPERATOR_TOL if inject else (_f64_tol(name, float(dA)) if dtype == "f64" else F32_TOL), seeds, label=label)
     finally:
         env.close()
 
@@ -183,7 +211,7 @@ def test_second_episode_keeps_dm_prev(golden_dir):
     from rlao_amd import _lib as L
     from rlao_amd.env import BatchedAOEnv
     g = np.load(os.path.join(golden_dir, "two_episodes.npz"))
-    for dtype, tol in (("f64", F64_TOL), ("f32", F32_TOL)):
+    for dtype, tol in (("f64", _f64_tol("tiny_sh", 1.7e-12 * 10)), ("f32", F32_TOL)):      # tiny_sh geometry (10x: two episodes)
         env = BatchedAOEnv(n_envs=1, device=0, dtype=dtype)
         env.set_params(_params(g), camera="ideal", wfs_type="shackhartmann", m2c=g["m2c"])
         for tag, seed in (("e1_", 5), ("e2_", 0)):

@@ -58,15 +58,6 @@ def test_atmosphere_tables(case):
         np.testing.assert_allclose(buff, g[f"s{seed}_buff"][i], atol=1e-13)
 
 
-def test_new_phase_screen(case):
-    g, p = case
-    t = calib.AtmosphereTables(p)
-    seed = int(g["cfg_seeds"][0])
-    for l in range(p.nLayer):
-        scr = calib.new_phase_screen(p.r0, p.L0, t.N, t.layer_D / t.N, seed + l)
-        np.testing.assert_allclose(scr, g[f"s{seed}_mapShift0"][l][1:-1, 1:-1], atol=1e-11)
-
-
 def test_dm_tables(case):
     g, p = case
     dm = calib.DMTables(p)
