@@ -12,11 +12,14 @@
 //
 // Stream layout (the fused step kernel and k_detector draw the same numbers):
 //   * the frame is cut into QUADS of 4 pixels; one Philox call per (quad, purpose) serves its 4 pixels, slot s gets word s:
-//       purpose 0  photon noise of a faint pixel (lambda < kPtrsFrom): ONE uniform, inversion by sequential search (exact)
-//       purpose 1  dark shot noise: one uniform, the same inversion
+//       purpose 0  photon noise: the uniform of a faint pixel (lambda < kPtrsFrom: inversion by sequential search, exact, ONE
+//                  uniform) or the proposal uniform U of a bright pixel's first PTRS round
+//       purpose 3  photon noise: the acceptance uniform V of a bright pixel's first PTRS round (Hoermann's transformed rejection,
+//                  exact; the algorithm NumPy's legacy generator uses from lambda = 10); its squeeze accepts ~86 % there and then
+//       purpose 1  dark shot noise: one uniform, inversion
 //       purpose 2  read-out noise: slots (0, 1) and (2, 3) share a Box-Muller pair (cos / sin branch)
-//   * a bright pixel (lambda >= kPtrsFrom) draws from a stream of its own, (pixel, env, frame, 16 + j): Hoermann's PTRS
-//     rejection sampler (exact; the algorithm NumPy's legacy generator uses), two uniforms per round.
+//   * a bright pixel whose first round is rejected (~8 %) goes on with a stream of its own, (pixel, env, frame, 16 + j), two
+//     uniforms per round.
 //   Quads: Shack-Hartmann frames with 6-pixel lenslets use the lane -> pixel map of the fused step kernel (a lane owns rows
 //   0..5 of the lenslet columns q and q + 3): rows 0..3 of a column are one quad, rows 4..5 of the columns c and c + 3 another.
 //   Any other frame: 4 consecutive pixels of a row.  A quad is named by the frame index of its slot-0 pixel.
@@ -57,7 +60,7 @@ typedef float f32x4d __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4d __attribute__((ext_vector_type(4)));
 
 constexpr float kPtrsFrom = 10.f;                              // PTRS is valid from lambda = 10 (NumPy switches there too)
-enum { kDrawPhoton = 0, kDrawDark = 1, kDrawReadout = 2, kDrawPixelStream = 16 };
+enum { kDrawPhoton = 0, kDrawDark = 1, kDrawReadout = 2, kDrawPhoton2 = 3, kDrawPixelStream = 16 };
 
 __device__ inline void quad_bits(uint32_t quad, uint32_t env, const DetectorCfg& d, uint32_t purpose, uint32_t (&o)[4]) {
     philox4x32(quad, env + d.env_offset, d.frame_counter, purpose, d.seed_lo, d.seed_hi, o);
@@ -96,34 +99,54 @@ __device__ inline float log_factorial(float k) {
     return k < 4.f ? small : st;
 }
 
-// Poisson(lam), lam >= kPtrsFrom: Hoermann's PTRS (exact).  The pixel's own stream: call j gives the uniforms of rounds 2j, 2j+1.
-__device__ inline float poisson_ptrs(float lam, uint32_t pixel, uint32_t env, const DetectorCfg& d) {
+// Poisson(lam), lam >= kPtrsFrom: Hoermann's PTRS (exact; the algorithm NumPy's legacy generator uses from lam = 10).
+// Round 0 takes its two uniforms from the pixel's words of the quad draws kDrawPhoton (U) and kDrawPhoton2 (V); a pixel that
+// round 0 rejects (~8 % of them) goes on with a stream of its own: call j gives the uniforms of rounds 1 + 2j, 2 + 2j.
+struct PtrsConst { float b, a, vr, lam; };
+__device__ inline PtrsConst ptrs_const(float lam) {
     // (1-ulp hardware reciprocals / square root: an IEEE division expands to ~10 instructions, and the constants of the
     //  hat function do not need the last bit)
-    const float slam = __builtin_amdgcn_sqrtf(lam), loglam = __logf(lam);
-    const float b = 0.931f + 2.53f * slam, a = -0.059f + 0.02483f * b;
-    const float invalpha = 1.1239f + 1.1328f * __builtin_amdgcn_rcpf(b - 3.4f), vr = 0.9277f - 3.6224f * __builtin_amdgcn_rcpf(b - 2.f);
-    const float log_invalpha = __logf(invalpha);
+    PtrsConst c;
+    c.lam = lam;
+    c.b = 0.931f + 2.53f * __builtin_amdgcn_sqrtf(lam);
+    c.a = -0.059f + 0.02483f * c.b;
+    c.vr = 0.9277f - 3.6224f * __builtin_amdgcn_rcpf(c.b - 2.f);
+    return c;
+}
+// the cheap part of a round: proposal k and the squeeze (accepts ~86 % of the proposals without a logarithm)
+__device__ inline bool ptrs_squeeze(const PtrsConst& c, uint32_t wu, uint32_t wv, float* kf, float* us_out, float* v_out) {
+    const float U = u01(wu) - 0.5f, V = u01(wv);
+    const float us = 0.5f - fabsf(U);
+    *kf = floorf((2.f * c.a * __builtin_amdgcn_rcpf(us) + c.b) * U + c.lam + 0.43f);
+    *us_out = us;
+    *v_out = V;
+    return us >= 0.07f && V <= c.vr;
+}
+// the full acceptance test of a proposal the squeeze did not accept
+__device__ inline bool ptrs_full(const PtrsConst& c, float kf, float us, float V, float loglam, float log_invalpha) {
+    if (kf < 0.f || (us < 0.013f && V > us)) return false;
+    const float rus = __builtin_amdgcn_rcpf(us);
+    return __logf(V) + log_invalpha - __logf(c.a * rus * rus + c.b) <= -c.lam + kf * loglam - log_factorial(kf);
+}
+__device__ inline float poisson_ptrs(float lam, uint32_t wu, uint32_t wv, uint32_t pixel, uint32_t env, const DetectorCfg& d) {
+    const PtrsConst c = ptrs_const(lam);
+    const float loglam = __logf(lam);
+    const float log_invalpha = __logf(1.1239f + 1.1328f * __builtin_amdgcn_rcpf(c.b - 3.4f));
     float result = floorf(lam + 0.5f);
-    bool done = false;
+    float kf, us, V;
+    bool done = ptrs_squeeze(c, wu, wv, &kf, &us, &V);
+    if (__any(!done)) done = done || ptrs_full(c, kf, us, V, loglam, log_invalpha);      // (everyone evaluates it: one wave)
+    if (done) result = kf;
     for (uint32_t call = 0; call < 32; ++call) {
+        if (!__any(!done)) break;
         uint32_t o[4];
         philox4x32(pixel, env + d.env_offset, d.frame_counter, kDrawPixelStream + call, d.seed_lo, d.seed_hi, o);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const float U = u01(o[2 * h]) - 0.5f, V = u01(o[2 * h + 1]);
-            const float us = 0.5f - fabsf(U);
-            const float rus = __builtin_amdgcn_rcpf(us);
-            const float kf = floorf((2.f * a * rus + b) * U + lam + 0.43f);
-            bool acc = us >= 0.07f && V <= vr;                                   // squeeze: ~86 % of the draws end here
-            if (__any(!done && !acc)) {                                         // someone needs the full test: everyone evaluates it
-                const bool cand = !(kf < 0.f || (us < 0.013f && V > us));
-                const bool full = __logf(V) + log_invalpha - __logf(a * rus * rus + b) <= -lam + kf * loglam - log_factorial(kf);
-                acc = acc || (cand && full);
-            }
+            bool acc = ptrs_squeeze(c, o[2 * h], o[2 * h + 1], &kf, &us, &V);
+            if (__any(!done && !acc)) acc = acc || ptrs_full(c, kf, us, V, loglam, log_invalpha);
             if (!done && acc) { result = kf; done = true; }
         }
-        if (!__any(!done)) break;
     }
     return result;
 }
@@ -171,8 +194,9 @@ template <bool PHOTON = true>
 __device__ inline void detector_quad(f32x4d& v, const uint32_t (&pix)[4], uint32_t quad, uint32_t env, const DetectorCfg& d, float rtab) {
     const u32x4d pv = {pix[0], pix[1], pix[2], pix[3]};
     if (PHOTON && d.photon_noise) {
-        uint32_t o[4];
+        uint32_t o[4], o2[4];
         quad_bits(quad, env, d, kDrawPhoton, o);
+        quad_bits(quad, env, d, kDrawPhoton2, o2);
 #pragma unroll 1
         for (int s = 0; s < 4; ++s) {
             const float lam = v[s];
@@ -180,8 +204,7 @@ __device__ inline void detector_quad(f32x4d& v, const uint32_t (&pix)[4], uint32
             float k = 0.f;
             if (__any(faint && lam > 0.f)) k = poisson_inversion(faint ? fmaxf(lam, 0.f) : 0.f, u01(word_of(o, s)), rtab);
             if (__any(!faint)) {
-                const uint32_t px = pv[s];
-                const float kb = poisson_ptrs(faint ? kPtrsFrom : lam, px, env, d);
+                const float kb = poisson_ptrs(faint ? kPtrsFrom : lam, word_of(o, s), word_of(o2, s), pv[s], env, d);
                 k = faint ? k : kb;
             }
             v[s] = k;
@@ -195,7 +218,7 @@ __device__ inline void detector_quad(f32x4d& v, const uint32_t (&pix)[4], uint32
         for (int s = 0; s < 4; ++s) {
             const uint32_t px = pv[s];
             dark[s] = d.dark_e < kPtrsFrom ? poisson_inversion(d.dark_e, u01(word_of(o, s)), rtab)
-                                           : poisson_ptrs(d.dark_e, px | 0x80000000u, env, d);
+                                           : poisson_ptrs(d.dark_e, word_of(o, s), ~word_of(o, s) * 0x9E3779B9u, px | 0x80000000u, env, d);
         }
     }
     if (d.readout_noise != 0.f) {

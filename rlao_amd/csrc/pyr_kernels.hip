@@ -25,7 +25,7 @@ constexpr size_t kFftLdsTarget = 40 * 1024;
 
 // P1: grid = (ceil(R / RB), chunk, E)
 template <typename T, int NFIX>
-__global__ void __launch_bounds__(256) k_pyr_rows(const PyrArgs<T> a) {
+__global__ void __launch_bounds__(256, sizeof(T) == 4 ? 4 : 1) k_pyr_rows(const PyrArgs<T> a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int N = a.N, NP = a.plan.np, R = a.R, RB = a.seq_per_block;
     cx<T>* A = reinterpret_cast<cx<T>*>(lds_raw);
@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(256) k_pyr_rows(const PyrArgs<T> a) {
 
 // P2: grid = (N / CB, chunk, E); CB columns per workgroup
 template <typename T, int NFIX>
-__global__ void __launch_bounds__(256) k_pyr_cols(const PyrArgs<T> a) {
+__global__ void __launch_bounds__(256, sizeof(T) == 4 ? 4 : 1) k_pyr_cols(const PyrArgs<T> a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int N = a.N, NP = a.plan.np, R = a.R, CB = a.seq_per_block;
     cx<T>* A = reinterpret_cast<cx<T>*>(lds_raw);
@@ -205,7 +205,7 @@ template int launch_psf<double>(const PyrArgs<double>&, double*, hipStream_t);
 
 // P3: grid = (cam, E); the nb = N / cam rows of one camera row, all modulation points of the chunk
 template <typename T, int NFIX>
-__global__ void __launch_bounds__(256) k_pyr_rows_inv(const PyrArgs<T> a, int accumulate) {
+__global__ void __launch_bounds__(256, sizeof(T) == 4 ? 4 : 1) k_pyr_rows_inv(const PyrArgs<T> a, int accumulate) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     // the nb rows of a camera row go through LDS in sub-batches of SB = seq_per_block rows (two buffers of SB sequences:
     // ~28 KB instead of 2 nb rows = 54 KB at nRes 528, i.e. 5 resident workgroups per CU instead of 2 -- the kernel waits on
@@ -282,7 +282,8 @@ __global__ void __launch_bounds__(256) k_pyr_slopes(const PyrSlopeArgs<T> a) {
     }
 }
 
-template <typename T, int NFIX>
+// NFIX: compile-time plan of the inverse row pass; NFIX12: of the row and column passes (0 = run-time plan)
+template <typename T, int NFIX, int NFIX12>
 int launch_pyramid_n(const PyrArgs<T>& base, int n_theta, int chunk, hipStream_t st) {
     PyrArgs<T> a = base;
     const int N = a.N, R = a.R;
@@ -301,9 +302,9 @@ int launch_pyramid_n(const PyrArgs<T>& base, int n_theta, int chunk, hipStream_t
     const size_t lds3 = (size_t)(2 * sb * NP + N) * sizeof(cx<T>) + (size_t)N * sizeof(T);
     const size_t lds1 = (size_t)(2 * rb * NP + N) * sizeof(cx<T>), lds2 = (size_t)(2 * cb * NP + N) * sizeof(cx<T>);
     if (lds1 > 64 * 1024)
-        AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyr_rows<T, NFIX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+        AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyr_rows<T, NFIX12>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
     if (lds2 > 64 * 1024)
-        AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyr_cols<T, NFIX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyr_cols<T, NFIX12>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     if (lds3 > 160 * 1024) return fail("pyramid: %d rows of nRes = %d per camera row do not fit in LDS", nb, N);
     if (lds3 > 64 * 1024)
         AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyr_rows_inv<T, NFIX>),
@@ -312,10 +313,10 @@ int launch_pyramid_n(const PyrArgs<T>& base, int n_theta, int chunk, hipStream_t
         a.theta0 = t0;
         a.n_theta_chunk = (n_theta - t0) < chunk ? (n_theta - t0) : chunk;
         a.seq_per_block = rb;
-        hipLaunchKernelGGL((k_pyr_rows<T, NFIX>), dim3(cdiv(R, rb), a.n_theta_chunk, a.n_env), dim3(256), lds1, st, a);
+        hipLaunchKernelGGL((k_pyr_rows<T, NFIX12>), dim3(cdiv(R, rb), a.n_theta_chunk, a.n_env), dim3(256), lds1, st, a);
         a.seq_per_block = cb;
         a.magic_seq = (unsigned)((1ull << 32) / (unsigned)cb) + 1u;
-        hipLaunchKernelGGL((k_pyr_cols<T, NFIX>), dim3(cdiv(N / cb, 8) * 8, a.n_theta_chunk, a.n_env), dim3(256), lds2, st, a);
+        hipLaunchKernelGGL((k_pyr_cols<T, NFIX12>), dim3(cdiv(N / cb, 8) * 8, a.n_theta_chunk, a.n_env), dim3(256), lds2, st, a);
         a.seq_per_block = sb;
         hipLaunchKernelGGL((k_pyr_rows_inv<T, NFIX>), dim3(a.cam, a.n_env), dim3(256), lds3, st, a, t0 > 0 ? 1 : 0);
         AO_HIP(hipGetLastError());
@@ -323,12 +324,14 @@ int launch_pyramid_n(const PyrArgs<T>& base, int n_theta, int chunk, hipStream_t
     return 0;
 }
 
-// the float32 transforms of the two lengths the reference's configurations use have compile-time plans (fft.hpp)
+// the float32 transforms of the two lengths the reference's configurations use have compile-time plans (fft.hpp).  At 528 the
+// row / column passes keep the run-time plan: fully unrolled around the radix-11 butterfly they need 194 registers (2 waves per
+// SIMD instead of 4: measured 5.7 -> 7.4 ms per step at 1024 envs) or spill.
 template <typename T>
 int launch_pyramid(const PyrArgs<T>& base, int n_theta, int chunk, hipStream_t st) {
-    if (sizeof(T) == 4 && base.N == 528 && base.plan.n_fac == 3) return launch_pyramid_n<T, 528>(base, n_theta, chunk, st);
-    if (sizeof(T) == 4 && base.N == 288 && base.plan.n_fac == 4) return launch_pyramid_n<T, 288>(base, n_theta, chunk, st);
-    return launch_pyramid_n<T, 0>(base, n_theta, chunk, st);
+    if (sizeof(T) == 4 && base.N == 528 && base.plan.n_fac == 3) return launch_pyramid_n<T, 528, 0>(base, n_theta, chunk, st);
+    if (sizeof(T) == 4 && base.N == 288 && base.plan.n_fac == 4) return launch_pyramid_n<T, 288, 288>(base, n_theta, chunk, st);
+    return launch_pyramid_n<T, 0, 0>(base, n_theta, chunk, st);
 }
 
 template <typename T>

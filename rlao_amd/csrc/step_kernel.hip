@@ -145,13 +145,6 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
     if (tid == 0) q_count_s = 0;
     lds_barrier();
     if (has_act) cimg[act_px] = act_c;
-    // the integrator's input of this lane's actuator (previous observation, or the caller's action): needed only in stage C
-    float act_prev = 0.f, dm_prev_c = 0.f;
-    if (a.fa.do_integrate) {
-        const size_t io = (size_t)e * (nA * nA) + (has_act ? act_px : 0);
-        act_prev = (a.fa.gain_from_obs != 0.f) ? a.fa.obs[io] : a.fa.action[io];
-        dm_prev_c = a.fa.dm_prev[(size_t)e * k.n_valid_act + (has_act ? tid : 0)];     // env.dm_prev (OOPAOEnv.py:508)
-    }
     float breg[2][KS];
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
@@ -481,56 +474,91 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
         for (int i = 12; i < 16; ++i) pxv[i] = 0.f;
         auto pick = [&](int p) { return pxv[p]; };
         auto put = [&](int p, float v) { pxv[p] = v; };
-        float2* queue = reinterpret_cast<float2*>(lds + L.mapt);              // {lambda -> count, frame pixel}; the layer tiles are dead
-        const int q_cap = (16 * WR * WC) / 2;
-        uint32_t bright = 0;
+        // queue of the bright pixels whose first PTRS round the squeeze did not accept: {lambda -> count, frame pixel, U word, V word}
+        f32x4s* queue = reinterpret_cast<f32x4s*>(lds + L.mapt);              // (the layer tiles are dead)
+        const int q_cap = (16 * WR * WC) / 4;
+        uint32_t pending = 0;
         int q_base = 0;
         if (a.det.photon_noise) {
 #pragma unroll 1
             for (int t = 0; t < 3; ++t) {
-                uint32_t o[4];
-                quad_bits(px0 + (t == 1 ? 3u : (t == 2 ? (uint32_t)(4 * R) : 0u)), (uint32_t)e, a.det, kDrawPhoton, o);
+                const uint32_t qid = px0 + (t == 1 ? 3u : (t == 2 ? (uint32_t)(4 * R) : 0u));
+                uint32_t o[4], o2[4];
+                quad_bits(qid, (uint32_t)e, a.det, kDrawPhoton, o);
+                quad_bits(qid, (uint32_t)e, a.det, kDrawPhoton2, o2);
 #pragma unroll 1
                 for (int sl4 = 0; sl4 < 4; ++sl4) {
                     const int p = pixel_of_slot(t, sl4);
                     const float v = pick(p);
                     const bool faint = !ok || !(v >= kPtrsFrom);
                     const float lam = faint && ok ? fmaxf(v, 0.f) : 0.f;
+                    const uint32_t wu = word_of(o, sl4), wv = word_of(o2, sl4);
                     float kf = 0.f;
-                    if (__any(lam > 0.f)) kf = poisson_inversion(lam, u01(word_of(o, sl4)), rtab);
+                    if (__any(lam > 0.f)) kf = poisson_inversion(lam, u01(wu), rtab);
+                    // bright pixels: proposal + squeeze of the first PTRS round, here and now (no logarithm: cheap enough to run for
+                    // every pixel position); only what the squeeze leaves undecided (~14 % of the bright pixels) is queued
+                    float kb, us, V;
+                    const bool sq = ptrs_squeeze(ptrs_const(faint ? kPtrsFrom : v), wu, wv, &kb, &us, &V);
                     if (faint) put(p, kf);
-                    bright |= faint ? 0u : 1u << p;
+                    else if (sq) put(p, kb);
+                    pending |= (faint || sq) ? 0u : 1u << p;
                 }
             }
-            const int nb = __popc(bright);
+            const int nb = __popc(pending);
             if (nb) q_base = atomicAdd(q_count, nb);
-            if (q_base + nb > q_cap) {                                        // queue full (a very bright star): this lane's own work
+            if (q_base + nb > q_cap) {                                        // queue full: this lane's own work
 #pragma unroll 1
                 for (int p = 0; p < 12; ++p)
-                    if (bright >> p & 1u) put(p, poisson_ptrs(pick(p), pix_of(p), (uint32_t)e, a.det));
-                bright = 0;
-            } else {
+                    if (pending >> p & 1u) {
+                        const int t = p < 4 ? 0 : (p >= 6 && p < 10 ? 1 : 2), sl4 = t == 0 ? p : (t == 1 ? p - 6 : (p < 6 ? p - 4 : p - 8));
+                        const uint32_t qid = px0 + (t == 1 ? 3u : (t == 2 ? (uint32_t)(4 * R) : 0u));
+                        uint32_t o[4], o2[4];
+                        quad_bits(qid, (uint32_t)e, a.det, kDrawPhoton, o);
+                        quad_bits(qid, (uint32_t)e, a.det, kDrawPhoton2, o2);
+                        put(p, poisson_ptrs(pick(p), word_of(o, sl4), word_of(o2, sl4), pix_of(p), (uint32_t)e, a.det));
+                    }
+                pending = 0;
+            } else if (nb) {
+                // the words of the undecided pixels again (3 quads x 2 draws would be 24 more live registers in the loop above)
                 int r = q_base;
 #pragma unroll 1
-                for (int p = 0; p < 12; ++p)
-                    if (bright >> p & 1u) queue[r++] = make_float2(pick(p), __uint_as_float(pix_of(p)));
+                for (int t = 0; t < 3; ++t) {
+                    const uint32_t mask_t = t == 0 ? 0x00fu : (t == 1 ? 0x3c0u : 0xc30u);
+                    if ((pending & mask_t) == 0) continue;
+                    const uint32_t qid = px0 + (t == 1 ? 3u : (t == 2 ? (uint32_t)(4 * R) : 0u));
+                    uint32_t o[4], o2[4];
+                    quad_bits(qid, (uint32_t)e, a.det, kDrawPhoton, o);
+                    quad_bits(qid, (uint32_t)e, a.det, kDrawPhoton2, o2);
+#pragma unroll 1
+                    for (int sl4 = 0; sl4 < 4; ++sl4) {
+                        const int p = pixel_of_slot(t, sl4);
+                        if (pending >> p & 1u)
+                            queue[r++] = f32x4s{pick(p), __uint_as_float(pix_of(p)), __uint_as_float(word_of(o, sl4)), __uint_as_float(word_of(o2, sl4))};
+                    }
+                }
             }
             AO_STAMP(23);
             lds_barrier();
             const int n_q = min(*q_count, q_cap);
             for (int i0 = 64 * w; i0 < n_q; i0 += 1024) {                      // whole waves: the sampler votes across the wave
                 const int i = i0 + lane;
-                const float2 it = queue[i < n_q ? i : 0];
-                const float kf = poisson_ptrs(i < n_q ? it.x : kPtrsFrom, __float_as_uint(it.y), (uint32_t)e, a.det);
-                if (i < n_q) queue[i].x = kf;
+                const f32x4s it = queue[i < n_q ? i : 0];
+                const float kf = poisson_ptrs(i < n_q ? it[0] : kPtrsFrom, __float_as_uint(it[2]), __float_as_uint(it[3]), __float_as_uint(it[1]),
+                                              (uint32_t)e, a.det);
+                if (i < n_q) queue[i][0] = kf;
             }
             AO_STAMP(2);
             lds_barrier();
-            {
+            if (pending) {
+                // the queue was filled quad by quad (t = 0, 1, 2; slots in order): read it back in the same order
                 int r = q_base;
 #pragma unroll 1
-                for (int p = 0; p < 12; ++p)
-                    if (bright >> p & 1u) put(p, queue[r++].x);
+                for (int t = 0; t < 3; ++t)
+#pragma unroll 1
+                    for (int sl4 = 0; sl4 < 4; ++sl4) {
+                        const int p = pixel_of_slot(t, sl4);
+                        if (pending >> p & 1u) put(p, queue[r++][0]);
+                    }
             }
         }
         // QE, dark shot noise, saturation, gain, read-out noise, ADC: quad by quad (dark_e < kPtrsFrom: checked by the host)
@@ -603,6 +631,14 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
         for (int j = 0; j < 10; ++j) mv[j] = row[(l16 + 16 * j < n4 ? l16 + 16 * j : 0) + late0];
     }
     const float ref0 = a.sc.ref[ok ? s : 0], ref1 = a.sc.ref[ok ? n_valid + s : 0];
+    // the integrator's inputs of this lane's actuator -- the previous observation (or the caller's action) and env.dm_prev
+    // (OOPAOEnv.py:508) -- are requested here too: held from the prologue on they were two more live registers across stages A and B
+    float act_prev = 0.f, dm_prev_c = 0.f;
+    if (a.fa.do_integrate) {
+        const size_t io = (size_t)e * (nA * nA) + (has_act ? act_px : 0) + late0;
+        act_prev = (a.fa.gain_from_obs != 0.f) ? a.fa.obs[io] : a.fa.action[io];
+        dm_prev_c = a.fa.dm_prev[(size_t)e * k.n_valid_act + (has_act ? tid : 0) + late0];
+    }
     for (int off = 32; off > 0; off >>= 1) {
         const float o = __shfl_down(mx, off);
         mx = o > mx ? o : mx;

@@ -391,6 +391,7 @@ class BatchedAOEnv:
         self.action_buffer = []
         self.atm = self.dm = self.tel = self.wfs = None
         self._shard = None
+        self._done = None
 
     # -- construction --------------------------------------------------------------------------------
     def set_params_file(self, param_file, oopao_path):
@@ -712,21 +713,28 @@ class BatchedAOEnv:
         return a.to(device=self.device, dtype=self.tdtype).contiguous()
 
     def step(self, i, action):
-        """MAIN/OOPAOEnv/OOPAOEnv.py:485-536.  Returns (obs, wfs_frame, reward, strehl, done, info)."""
+        """MAIN/OOPAOEnv/OOPAOEnv.py:485-536.  Returns (obs, wfs_frame, reward, strehl, done, info).  Every call hands out NEW
+        tensors, as the reference hands out new arrays (a replay buffer may keep them): the library writes straight into them, so
+        there is no copy kernel behind the call -- only the allocator."""
+        torch = _torch()
         a = self._action_tensor(action)
-        fr = self._frame
+        N, A_ = self.n_envs, self.nActuator
+        obs = torch.empty((N, A_, A_), device=self.device, dtype=self.tdtype)
+        reward = torch.empty((N,), device=self.device, dtype=self.tdtype)
+        strehl = torch.empty((N,), device=self.device, dtype=self.tdtype)
+        fr = torch.empty((N, self.cam_res, self.cam_res), device=self.device, dtype=self.tdtype) if self.return_frame else None
         L.check(self._shard.lib.aoenv_step(
-            self._shard.h, int(i), C.c_void_p(a.data_ptr()), C.c_void_p(self._obs.data_ptr()),
-            C.c_void_p(fr.data_ptr()) if fr is not None else None, C.c_void_p(self._reward.data_ptr()),
-            C.c_void_p(self._strehl.data_ptr()), C.c_void_p(self._stream())))
-        strehl = self._strehl.clone()
+            self._shard.h, int(i), C.c_void_p(a.data_ptr()), C.c_void_p(obs.data_ptr()),
+            C.c_void_p(fr.data_ptr()) if fr is not None else None, C.c_void_p(reward.data_ptr()),
+            C.c_void_p(strehl.data_ptr()), C.c_void_p(self._stream())))
+        self._obs, self._reward, self._strehl, self._frame = obs, reward, strehl, fr
         self.SR.append(strehl)
         if self.output == "numpy":
             s = float(strehl[0])
-            return (self._out(self._obs), None if fr is None else self._out(fr), float(self._reward[0]), s, False,
-                    {"strehl": s})
-        done = _torch().zeros(self.n_envs, dtype=_torch().bool, device=self.device)
-        return self._obs.clone(), (None if fr is None else fr.clone()), self._reward.clone(), strehl, done, {"strehl": strehl}
+            return (self._out(obs), None if fr is None else self._out(fr), float(reward[0]), s, False, {"strehl": s})
+        if self._done is None:
+            self._done = torch.zeros(N, dtype=torch.bool, device=self.device)      # never terminal (OOPAOEnv.py:531): one shared tensor
+        return obs, fr, reward, strehl, self._done, {"strehl": strehl}
 
     def run_integrator(self, i0: int, n_steps: int, gain=None):
         """On-device closed loop of MAIN/integrator_oopao_razor.py:66-91: ``action = gainCL * obs`` fused into
