@@ -128,15 +128,14 @@ __device__ inline bool ptrs_full(const PtrsConst& c, float kf, float us, float V
     const float rus = __builtin_amdgcn_rcpf(us);
     return __logf(V) + log_invalpha - __logf(c.a * rus * rus + c.b) <= -c.lam + kf * loglam - log_factorial(kf);
 }
-__device__ inline float poisson_ptrs(float lam, uint32_t wu, uint32_t wv, uint32_t pixel, uint32_t env, const DetectorCfg& d) {
-    const PtrsConst c = ptrs_const(lam);
-    const float loglam = __logf(lam);
-    const float log_invalpha = __logf(1.1239f + 1.1328f * __builtin_amdgcn_rcpf(c.b - 3.4f));
-    float result = floorf(lam + 0.5f);
+struct PtrsLogs { float loglam, log_invalpha; };
+__device__ inline PtrsLogs ptrs_logs(const PtrsConst& c) {
+    return {__logf(c.lam), __logf(1.1239f + 1.1328f * __builtin_amdgcn_rcpf(c.b - 3.4f))};
+}
+// rounds 1, 2, ... of a pixel whose round 0 was rejected: its own stream, until accepted.  Whole waves call this together.
+__device__ inline float poisson_ptrs_rounds(const PtrsConst& c, const PtrsLogs& g, bool done, float result, uint32_t pixel, uint32_t env,
+                                            const DetectorCfg& d) {
     float kf, us, V;
-    bool done = ptrs_squeeze(c, wu, wv, &kf, &us, &V);
-    if (__any(!done)) done = done || ptrs_full(c, kf, us, V, loglam, log_invalpha);      // (everyone evaluates it: one wave)
-    if (done) result = kf;
     for (uint32_t call = 0; call < 32; ++call) {
         if (!__any(!done)) break;
         uint32_t o[4];
@@ -144,11 +143,19 @@ __device__ inline float poisson_ptrs(float lam, uint32_t wu, uint32_t wv, uint32
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             bool acc = ptrs_squeeze(c, o[2 * h], o[2 * h + 1], &kf, &us, &V);
-            if (__any(!done && !acc)) acc = acc || ptrs_full(c, kf, us, V, loglam, log_invalpha);
+            if (__any(!done && !acc)) acc = acc || ptrs_full(c, kf, us, V, g.loglam, g.log_invalpha);
             if (!done && acc) { result = kf; done = true; }
         }
     }
     return result;
+}
+__device__ inline float poisson_ptrs(float lam, uint32_t wu, uint32_t wv, uint32_t pixel, uint32_t env, const DetectorCfg& d) {
+    const PtrsConst c = ptrs_const(lam);
+    const PtrsLogs g = ptrs_logs(c);
+    float kf, us, V;
+    bool done = ptrs_squeeze(c, wu, wv, &kf, &us, &V);
+    if (__any(!done)) done = done || ptrs_full(c, kf, us, V, g.loglam, g.log_invalpha);      // (everyone evaluates it: one wave)
+    return poisson_ptrs_rounds(c, g, done, done ? kf : floorf(lam + 0.5f), pixel, env, d);
 }
 
 // standard normals of a quad's read-out draw: slots (0, 1) and (2, 3) are the cos / sin branches of one Box-Muller pair each

@@ -99,8 +99,9 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
     __shared__ double red[4][16];
     __shared__ double red_tail[16];
     __shared__ float red_mx[16];
-    __shared__ int q_count_s;                                    // bright pixels queued for the rejection sampler (stage B camera)
-    int* q_count = &q_count_s;
+    __shared__ int q_count_s[2];                                 // stage B camera: entries of the queues Q0 and Q1
+    int* q_count = &q_count_s[0];
+    int* q1_count = &q_count_s[1];
 
     const int e = blockIdx.x;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
@@ -142,7 +143,7 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
     for (int i = tid; i < 2 * PR * SS; i += 1024) s1[i] = 0.f;
     if (tid < n_sub * n_sub) slot_s[tid] = slot_v;
     for (int i = tid + 1024; i < n_sub * n_sub; i += 1024) slot_s[i] = a.slot_of[i];
-    if (tid == 0) q_count_s = 0;
+    if (tid < 2) q_count_s[tid] = 0;
     lds_barrier();
     if (has_act) cimg[act_px] = act_c;
     float breg[2][KS];
@@ -474,9 +475,17 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
         for (int i = 12; i < 16; ++i) pxv[i] = 0.f;
         auto pick = [&](int p) { return pxv[p]; };
         auto put = [&](int p, float v) { pxv[p] = v; };
-        // queue of the bright pixels whose first PTRS round the squeeze did not accept: {lambda -> count, frame pixel, U word, V word}
-        f32x4s* queue = reinterpret_cast<f32x4s*>(lds + L.mapt);              // (the layer tiles are dead)
-        const int q_cap = (16 * WR * WC) / 4;
+        // Bright pixels the squeeze leaves undecided (35-65 % of them at 10-100 photons) are finished by the whole workgroup, in two
+        // dense passes -- per lane they kept a wave in the rejection loop until its slowest lane was through, with most lanes idle:
+        //   Q0 {lambda, frame pixel, U word, V word}: the full acceptance test of round 0 for every entry, one per lane and pass;
+        //   Q1 {lambda, frame pixel, index in Q0}: what round 0 rejects (~40 % of Q0) goes on with its own stream, about one entry
+        //      per lane, until accepted;  res[index in Q0]: the counts, picked up by the owners.
+        // Q0 lives where E0 was (dead once every wave has its spots: the barrier below), res and Q1 where the layer tiles were.
+        f32x4s* q0 = reinterpret_cast<f32x4s*>(lds + L.e0);
+        const int q0_cap = min((L.total - L.e0) / 4, 7296);
+        float* res = lds + L.mapt;
+        float* q1 = lds + L.mapt + q0_cap;                                     // 3 words per entry
+        const int q1_cap = (16 * WR * WC - q0_cap) / 3;
         uint32_t pending = 0;
         int q_base = 0;
         if (a.det.photon_noise) {
@@ -496,7 +505,7 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
                     float kf = 0.f;
                     if (__any(lam > 0.f)) kf = poisson_inversion(lam, u01(wu), rtab);
                     // bright pixels: proposal + squeeze of the first PTRS round, here and now (no logarithm: cheap enough to run for
-                    // every pixel position); only what the squeeze leaves undecided (~14 % of the bright pixels) is queued
+                    // every pixel position)
                     float kb, us, V;
                     const bool sq = ptrs_squeeze(ptrs_const(faint ? kPtrsFrom : v), wu, wv, &kb, &us, &V);
                     if (faint) put(p, kf);
@@ -506,7 +515,9 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
             }
             const int nb = __popc(pending);
             if (nb) q_base = atomicAdd(q_count, nb);
-            if (q_base + nb > q_cap) {                                        // queue full: this lane's own work
+            AO_STAMP(23);
+            lds_barrier();                                                    // every wave has its spots: E0 is free
+            if (q_base + nb > q0_cap) {                                       // queue full: this lane's own work
 #pragma unroll 1
                 for (int p = 0; p < 12; ++p)
                     if (pending >> p & 1u) {
@@ -533,19 +544,46 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
                     for (int sl4 = 0; sl4 < 4; ++sl4) {
                         const int p = pixel_of_slot(t, sl4);
                         if (pending >> p & 1u)
-                            queue[r++] = f32x4s{pick(p), __uint_as_float(pix_of(p)), __uint_as_float(word_of(o, sl4)), __uint_as_float(word_of(o2, sl4))};
+                            q0[r++] = f32x4s{pick(p), __uint_as_float(pix_of(p)), __uint_as_float(word_of(o, sl4)), __uint_as_float(word_of(o2, sl4))};
                     }
                 }
             }
-            AO_STAMP(23);
             lds_barrier();
-            const int n_q = min(*q_count, q_cap);
-            for (int i0 = 64 * w; i0 < n_q; i0 += 1024) {                      // whole waves: the sampler votes across the wave
+            const int n_q0 = min(*q_count, q0_cap);
+            // pass 1: round 0's full test, one entry per lane; accepted -> res, rejected -> Q1 (or, Q1 full, finished on the spot)
+            for (int i0 = 64 * w; i0 < n_q0; i0 += 1024) {
                 const int i = i0 + lane;
-                const f32x4s it = queue[i < n_q ? i : 0];
-                const float kf = poisson_ptrs(i < n_q ? it[0] : kPtrsFrom, __float_as_uint(it[2]), __float_as_uint(it[3]), __float_as_uint(it[1]),
-                                              (uint32_t)e, a.det);
-                if (i < n_q) queue[i][0] = kf;
+                const bool live = i < n_q0;
+                const f32x4s it = q0[live ? i : 0];
+                const PtrsConst c = ptrs_const(live ? it[0] : kPtrsFrom);
+                const PtrsLogs g = ptrs_logs(c);
+                float kf, us, V;
+                bool done = ptrs_squeeze(c, __float_as_uint(it[2]), __float_as_uint(it[3]), &kf, &us, &V);     // (known: not accepted)
+                done = done || ptrs_full(c, kf, us, V, g.loglam, g.log_invalpha);
+                int slot1 = -1;
+                if (live && !done) slot1 = atomicAdd(q1_count, 1);
+                if (slot1 >= 0 && slot1 < q1_cap) {
+                    q1[3 * slot1] = it[0];
+                    q1[3 * slot1 + 1] = it[1];
+                    q1[3 * slot1 + 2] = __int_as_float(i);
+                    done = true;                                              // (its count comes from pass 2)
+                    kf = -1.f;
+                }
+                if (__any(live && !done))                                     // Q1 full: finished here, by the lanes that drew a slot beyond it
+                    kf = poisson_ptrs_rounds(c, g, !live || done, kf, __float_as_uint(it[1]), (uint32_t)e, a.det);
+                if (live && !(slot1 >= 0 && slot1 < q1_cap)) res[i] = kf;
+            }
+            lds_barrier();
+            const int n_q1 = min(*q1_count, q1_cap);
+            for (int i0 = 64 * w; i0 < n_q1; i0 += 1024) {                     // pass 2: whole waves, the sampler votes across the wave
+                const int i = i0 + lane;
+                const bool live = i < n_q1;
+                const float lam1 = live ? q1[3 * i] : kPtrsFrom;
+                const uint32_t pix1 = __float_as_uint(q1[3 * (live ? i : 0) + 1]);
+                const int orig = __float_as_int(q1[3 * (live ? i : 0) + 2]);
+                const PtrsConst c = ptrs_const(lam1);
+                const float kf = poisson_ptrs_rounds(c, ptrs_logs(c), !live, floorf(lam1 + 0.5f), pix1, (uint32_t)e, a.det);
+                if (live) res[orig] = kf;
             }
             AO_STAMP(2);
             lds_barrier();
@@ -557,7 +595,7 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
 #pragma unroll 1
                     for (int sl4 = 0; sl4 < 4; ++sl4) {
                         const int p = pixel_of_slot(t, sl4);
-                        if (pending >> p & 1u) put(p, queue[r++][0]);
+                        if (pending >> p & 1u) put(p, res[r++]);
                     }
             }
         }
