@@ -87,6 +87,25 @@ __device__ inline float poisson_inversion(float lam, float u, float rtab) {
     return k;
 }
 
+// The same for TWO pixels of a lane at once, as packed float32 pairs (v_pk_mul_f32 / v_pk_add_f32): the recurrence of the
+// probability and the running sum cost one instruction per pair instead of one per pixel.
+typedef float f32x2d __attribute__((ext_vector_type(2)));
+__device__ inline f32x2d poisson_inversion2(f32x2d lam, f32x2d u, float rtab) {
+    f32x2d p = {__expf(-lam.x), __expf(-lam.y)}, cdf = p, k = {0.f, 0.f};
+    for (int k0 = 0; k0 < 64; k0 += 4) {
+        if (!__any(u.x > cdf.x || u.y > cdf.y)) break;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            k.x += u.x > cdf.x ? 1.f : 0.f;
+            k.y += u.y > cdf.y ? 1.f : 0.f;
+            const float inv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rtab), k0 + j));
+            p *= lam * inv;
+            cdf += p;
+        }
+    }
+    return k;
+}
+
 // log(k!) for integer-valued k >= 0.
 // (lgammaf costs ~10x more instructions, and the PTRS acceptance test below runs for every bright pixel of every frame.)
 __device__ inline float log_factorial(float k) {

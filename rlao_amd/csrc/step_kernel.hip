@@ -24,9 +24,9 @@
 
 // Diagnostic build only (-DAO_STEP_STAMPS): wave 0 of each workgroup stamps s_memtime at the stage boundaries.
 #ifdef AO_STEP_STAMPS
-namespace ao { __device__ unsigned long long g_stamps[1024 * 24]; __device__ unsigned long long g_wstamps[256 * 16 * 8]; }
+namespace ao { __device__ unsigned long long g_stamps[1024 * 32]; __device__ unsigned long long g_wstamps[256 * 16 * 8]; }
 #define AO_WSTAMP(i) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 256) ::ao::g_wstamps[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#define AO_STAMP(i) do { if (tid == 0 && e < 1024) ::ao::g_stamps[e * 24 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define AO_STAMP(i) do { if (tid == 0 && e < 1024) ::ao::g_stamps[e * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define AO_STAMP(i) do { } while (0)
 #define AO_WSTAMP(i) do { } while (0)
@@ -416,7 +416,6 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
         red[3][w] = q_res;
     }
     lds_barrier();                                             // E0 complete, red complete, s1 dead
-    for (int i = tid; i < nA * nA; i += 1024) img_s[i] = 0.f;    // (aliases s1) zero at non-actuators: vec_to_img
     AO_STAMP(14);
     AO_WSTAMP(4);
     if (tid == 1023) {                                           // an idle lane: runs beside the spots of the other waves
@@ -477,17 +476,18 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
         auto put = [&](int p, float v) { pxv[p] = v; };
         // Bright pixels the squeeze leaves undecided (35-65 % of them at 10-100 photons) are finished by the whole workgroup, in two
         // dense passes -- per lane they kept a wave in the rejection loop until its slowest lane was through, with most lanes idle:
-        //   Q0 {lambda, frame pixel, U word, V word}: the full acceptance test of round 0 for every entry, one per lane and pass;
+        //   Q0 {lambda, frame pixel, U word, V word}, filled as the pixels are met (one LDS atomic per entry; the pixel's register
+        //      keeps the entry's index): the full acceptance test of round 0 for every entry, one per lane and pass;
         //   Q1 {lambda, frame pixel, index in Q0}: what round 0 rejects (~40 % of Q0) goes on with its own stream, about one entry
         //      per lane, until accepted;  res[index in Q0]: the counts, picked up by the owners.
-        // Q0 lives where E0 was (dead once every wave has its spots: the barrier below), res and Q1 where the layer tiles were.
-        f32x4s* q0 = reinterpret_cast<f32x4s*>(lds + L.e0);
-        const int q0_cap = min((L.total - L.e0) / 4, 7296);
-        float* res = lds + L.mapt;
-        float* q1 = lds + L.mapt + q0_cap;                                     // 3 words per entry
-        const int q1_cap = (16 * WR * WC - q0_cap) / 3;
-        uint32_t pending = 0;
-        int q_base = 0;
+        // Q0 lives where Gy C and the layer tiles were (dead since stage A); res and Q1 where E0 was (dead once every wave has its
+        // spots: the barrier below).
+        f32x4s* q0 = reinterpret_cast<f32x4s*>(lds + L.s1);
+        const int q0_cap = (L.slot - L.s1) / 4;
+        float* res = lds + L.e0;
+        float* q1 = lds + L.e0 + q0_cap;                                       // 3 words per entry
+        const int q1_cap = (L.total - L.e0 - q0_cap) / 3;
+        uint32_t pending = 0, spilled = 0;                                   // spilled: bright, undecided, and Q0 was full
         if (a.det.photon_noise) {
 #pragma unroll 1
             for (int t = 0; t < 3; ++t) {
@@ -496,31 +496,48 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
                 quad_bits(qid, (uint32_t)e, a.det, kDrawPhoton, o);
                 quad_bits(qid, (uint32_t)e, a.det, kDrawPhoton2, o2);
 #pragma unroll 1
-                for (int sl4 = 0; sl4 < 4; ++sl4) {
-                    const int p = pixel_of_slot(t, sl4);
-                    const float v = pick(p);
-                    const bool faint = !ok || !(v >= kPtrsFrom);
-                    const float lam = faint && ok ? fmaxf(v, 0.f) : 0.f;
-                    const uint32_t wu = word_of(o, sl4), wv = word_of(o2, sl4);
-                    float kf = 0.f;
-                    if (__any(lam > 0.f)) kf = poisson_inversion(lam, u01(wu), rtab);
-                    // bright pixels: proposal + squeeze of the first PTRS round, here and now (no logarithm: cheap enough to run for
-                    // every pixel position)
-                    float kb, us, V;
-                    const bool sq = ptrs_squeeze(ptrs_const(faint ? kPtrsFrom : v), wu, wv, &kb, &us, &V);
-                    if (faint) put(p, kf);
-                    else if (sq) put(p, kb);
-                    pending |= (faint || sq) ? 0u : 1u << p;
+                for (int h = 0; h < 2; ++h) {                                 // two pixels per turn: the inversion runs on packed pairs
+                    const int pa = pixel_of_slot(t, 2 * h), pb = pixel_of_slot(t, 2 * h + 1);
+                    const float va = pick(pa), vb = pick(pb);
+                    const bool fa_ = !ok || !(va >= kPtrsFrom), fb_ = !ok || !(vb >= kPtrsFrom);
+                    const uint32_t wua = word_of(o, 2 * h), wub = word_of(o, 2 * h + 1), wva = word_of(o2, 2 * h), wvb = word_of(o2, 2 * h + 1);
+                    const f32x2d lam2 = {fa_ && ok ? fmaxf(va, 0.f) : 0.f, fb_ && ok ? fmaxf(vb, 0.f) : 0.f};
+                    f32x2d k2 = {0.f, 0.f};
+                    if (__any(lam2.x > 0.f || lam2.y > 0.f)) k2 = poisson_inversion2(lam2, f32x2d{u01(wua), u01(wub)}, rtab);
+                    // bright pixels: proposal + squeeze of the first PTRS round, here and now (no logarithm)
+                    if (__any(!fa_ || !fb_)) {
+#pragma unroll
+                        for (int z = 0; z < 2; ++z) {
+                            const bool faint = z ? fb_ : fa_;
+                            const float v = z ? vb : va;
+                            const uint32_t wu = z ? wub : wua, wv = z ? wvb : wva;
+                            const int p = z ? pb : pa;
+                            float kb, us, V;
+                            const bool sq = ptrs_squeeze(ptrs_const(faint ? kPtrsFrom : v), wu, wv, &kb, &us, &V);
+                            float outv = faint ? (z ? k2.y : k2.x) : kb;
+                            if (!faint && !sq) {
+                                const int idx = atomicAdd(q_count, 1);
+                                if (idx < q0_cap) {
+                                    q0[idx] = f32x4s{v, __uint_as_float(pix_of(p)), __uint_as_float(wu), __uint_as_float(wv)};
+                                    outv = __int_as_float(idx);
+                                    pending |= 1u << p;
+                                } else {
+                                    outv = v;
+                                    spilled |= 1u << p;
+                                }
+                            }
+                            put(p, outv);
+                        }
+                    } else {
+                        put(pa, k2.x);
+                        put(pb, k2.y);
+                    }
                 }
             }
-            const int nb = __popc(pending);
-            if (nb) q_base = atomicAdd(q_count, nb);
-            AO_STAMP(23);
-            lds_barrier();                                                    // every wave has its spots: E0 is free
-            if (q_base + nb > q0_cap) {                                       // queue full: this lane's own work
+            if (__any(spilled != 0)) {                                        // Q0 full (a very bright star): these lanes' own work
 #pragma unroll 1
                 for (int p = 0; p < 12; ++p)
-                    if (pending >> p & 1u) {
+                    if (spilled >> p & 1u) {
                         const int t = p < 4 ? 0 : (p >= 6 && p < 10 ? 1 : 2), sl4 = t == 0 ? p : (t == 1 ? p - 6 : (p < 6 ? p - 4 : p - 8));
                         const uint32_t qid = px0 + (t == 1 ? 3u : (t == 2 ? (uint32_t)(4 * R) : 0u));
                         uint32_t o[4], o2[4];
@@ -528,27 +545,10 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
                         quad_bits(qid, (uint32_t)e, a.det, kDrawPhoton2, o2);
                         put(p, poisson_ptrs(pick(p), word_of(o, sl4), word_of(o2, sl4), pix_of(p), (uint32_t)e, a.det));
                     }
-                pending = 0;
-            } else if (nb) {
-                // the words of the undecided pixels again (3 quads x 2 draws would be 24 more live registers in the loop above)
-                int r = q_base;
-#pragma unroll 1
-                for (int t = 0; t < 3; ++t) {
-                    const uint32_t mask_t = t == 0 ? 0x00fu : (t == 1 ? 0x3c0u : 0xc30u);
-                    if ((pending & mask_t) == 0) continue;
-                    const uint32_t qid = px0 + (t == 1 ? 3u : (t == 2 ? (uint32_t)(4 * R) : 0u));
-                    uint32_t o[4], o2[4];
-                    quad_bits(qid, (uint32_t)e, a.det, kDrawPhoton, o);
-                    quad_bits(qid, (uint32_t)e, a.det, kDrawPhoton2, o2);
-#pragma unroll 1
-                    for (int sl4 = 0; sl4 < 4; ++sl4) {
-                        const int p = pixel_of_slot(t, sl4);
-                        if (pending >> p & 1u)
-                            q0[r++] = f32x4s{pick(p), __uint_as_float(pix_of(p)), __uint_as_float(word_of(o, sl4)), __uint_as_float(word_of(o2, sl4))};
-                    }
-                }
             }
-            lds_barrier();
+            AO_STAMP(23);
+            lds_barrier();                                                    // every wave has its spots: E0 is free; Q0 is complete
+            AO_STAMP(6);
             const int n_q0 = min(*q_count, q0_cap);
             // pass 1: round 0's full test, one entry per lane; accepted -> res, rejected -> Q1 (or, Q1 full, finished on the spot)
             for (int i0 = 64 * w; i0 < n_q0; i0 += 1024) {
@@ -562,19 +562,22 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
                 done = done || ptrs_full(c, kf, us, V, g.loglam, g.log_invalpha);
                 int slot1 = -1;
                 if (live && !done) slot1 = atomicAdd(q1_count, 1);
-                if (slot1 >= 0 && slot1 < q1_cap) {
+                const bool queued = slot1 >= 0 && slot1 < q1_cap;
+                if (queued) {
                     q1[3 * slot1] = it[0];
                     q1[3 * slot1 + 1] = it[1];
                     q1[3 * slot1 + 2] = __int_as_float(i);
-                    done = true;                                              // (its count comes from pass 2)
-                    kf = -1.f;
                 }
-                if (__any(live && !done))                                     // Q1 full: finished here, by the lanes that drew a slot beyond it
-                    kf = poisson_ptrs_rounds(c, g, !live || done, kf, __float_as_uint(it[1]), (uint32_t)e, a.det);
-                if (live && !(slot1 >= 0 && slot1 < q1_cap)) res[i] = kf;
+                if (__any(live && !done && !queued))                          // Q1 full: finished here, by the lanes that drew a slot beyond it
+                    kf = poisson_ptrs_rounds(c, g, !live || done || queued, kf, __float_as_uint(it[1]), (uint32_t)e, a.det);
+                if (live && !queued) res[i] = kf;
             }
             lds_barrier();
+            AO_STAMP(12);
             const int n_q1 = min(*q1_count, q1_cap);
+#ifdef AO_STEP_STAMPS
+            if (tid == 0 && e < 1024) { ::ao::g_stamps[e * 32 + 24] = (unsigned long long)n_q0; ::ao::g_stamps[e * 32 + 25] = (unsigned long long)n_q1; }
+#endif
             for (int i0 = 64 * w; i0 < n_q1; i0 += 1024) {                     // pass 2: whole waves, the sampler votes across the wave
                 const int i = i0 + lane;
                 const bool live = i < n_q1;
@@ -588,15 +591,9 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
             AO_STAMP(2);
             lds_barrier();
             if (pending) {
-                // the queue was filled quad by quad (t = 0, 1, 2; slots in order): read it back in the same order
-                int r = q_base;
 #pragma unroll 1
-                for (int t = 0; t < 3; ++t)
-#pragma unroll 1
-                    for (int sl4 = 0; sl4 < 4; ++sl4) {
-                        const int p = pixel_of_slot(t, sl4);
-                        if (pending >> p & 1u) put(p, res[r++]);
-                    }
+                for (int p = 0; p < 12; ++p)
+                    if (pending >> p & 1u) put(p, res[__float_as_int(pick(p))]);
             }
         }
         // QE, dark shot noise, saturation, gain, read-out noise, ADC: quad by quad (dark_e < kPtrsFrom: checked by the host)
@@ -638,6 +635,9 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
         }
     }
     AO_STAMP(15);
+    // (aliases s1 -- and the camera's queue Q0, which is finished with here) zero at non-actuators: vec_to_img.  Stage C writes
+    // the actuators' values two barriers from here.
+    for (int i = tid; i < nA * nA; i += 1024) img_s[i] = 0.f;
     if (a.det.active && (a.det.dark_e > 0.f || a.det.readout_noise != 0.f)) {
         // the camera also reads out the pixels of the lenslets that are not valid (no light): dark + read-out noise, ADC
         const float rtab = recip_table_lane();
@@ -804,7 +804,7 @@ extern "C" int aoenv_debug_wstamps(unsigned long long* h_out) {
     return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_wstamps), sizeof(unsigned long long) * 256 * 16 * 8) == hipSuccess ? 0 : 1;
 }
 extern "C" int aoenv_debug_stamps(unsigned long long* h_out, int n_env) {
-    return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 24 * (size_t)n_env) == hipSuccess ? 0 : 1;
+    return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 32 * (size_t)n_env) == hipSuccess ? 0 : 1;
 }
 #endif
 

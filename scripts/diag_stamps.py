@@ -14,7 +14,7 @@ print("camera:", CAM)
 env.generate_new_phase_screen(17); env.dm.coefs = 0; env.measure(); env.reset_soft()
 env.run_integrator(0, 50); torch.cuda.synchronize()
 lib = L.load()
-st = np.zeros((min(N, 1024), 24), dtype=np.uint64)
+st = np.zeros((min(N, 1024), 32), dtype=np.uint64)
 assert lib.aoenv_debug_stamps(st.ctypes.data_as(C.c_void_p), st.shape[0]) == 0
 st = st.astype(np.int64)
 names = {0: "start", 1: "p0 sync", 3: "p0 s1 (mfma) + amp loads issued", 4: "p0 tile in LDS", 5: "p0 interp done",
@@ -22,7 +22,11 @@ names = {0: "start", 1: "p0 sync", 3: "p0 s1 (mfma) + amp loads issued", 4: "p0 
          13: "p1 epilogue done", 14: "E0 sync", 22: "spots (DFT) done", 23: "camera: faint pixels drawn, queue written",
          2: "camera: queue drawn (wave 0)", 15: "camera finished, frame stored", 16: "max sync", 17: "centroid sync",
          19: "tail: t = M s", 20: "tail: o = M2C t, integrator", 21: "tail: obs write + reduce", 18: "tail: scalar finish"}
-idx = [0, 1, 3, 4, 5, 7, 9, 10, 11, 13, 14, 22] + ([23, 2] if CAM != "ideal" else []) + [15, 16, 17, 19, 20, 21, 18]
+idx = [0, 1, 3, 4, 5, 7, 9, 10, 11, 13, 14, 22] + ([23, 6, 12, 2] if CAM != "ideal" else []) + [15, 16, 17, 19, 18]
+names.update({23: "camera: faint + squeeze done (wave 0)", 6: "camera: barrier (E0 free)", 8: "camera: Q0 written + barrier",
+              12: "camera: pass 1 (round 0 full test) + barrier", 2: "camera: pass 2 (own streams), wave 0"})
+if CAM != "ideal":
+    print("queue sizes (median over envs): Q0", np.median(st[:, 24]), " Q1", np.median(st[:, 25]))
 names[1] = "prologue + s1 (mfma)"; names[3] = "p0 amp loads issued, sync"; names[9] = "p1 amp loads issued, sync"
 prev = None
 for i in idx:
