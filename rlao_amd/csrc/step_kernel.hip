@@ -515,8 +515,15 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
                             float kb, us, V;
                             const bool sq = ptrs_squeeze(ptrs_const(faint ? kPtrsFrom : v), wu, wv, &kb, &us, &V);
                             float outv = faint ? (z ? k2.y : k2.x) : kb;
-                            if (!faint && !sq) {
-                                const int idx = atomicAdd(q_count, 1);
+                            // one LDS atomic per wave and pixel position, not one per undecided pixel (2500 adds to one
+                            // address per frame were a queue of their own): ballot + popcount hand out the wave's indices
+                            const bool undecided = !faint && !sq;
+                            const unsigned long long bal = __ballot(undecided);
+                            int idx_base = 0;
+                            if (bal != 0ull && lane == 0) idx_base = atomicAdd(q_count, __popcll(bal));
+                            idx_base = __builtin_amdgcn_readfirstlane(idx_base);
+                            if (undecided) {
+                                const int idx = idx_base + __popcll(bal & ((1ull << lane) - 1ull));
                                 if (idx < q0_cap) {
                                     q0[idx] = f32x4s{v, __uint_as_float(pix_of(p)), __uint_as_float(wu), __uint_as_float(wv)};
                                     outv = __int_as_float(idx);
@@ -561,7 +568,14 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
                 bool done = ptrs_squeeze(c, __float_as_uint(it[2]), __float_as_uint(it[3]), &kf, &us, &V);     // (known: not accepted)
                 done = done || ptrs_full(c, kf, us, V, g.loglam, g.log_invalpha);
                 int slot1 = -1;
-                if (live && !done) slot1 = atomicAdd(q1_count, 1);
+                {
+                    const bool rej = live && !done;
+                    const unsigned long long bal = __ballot(rej);
+                    int b1 = 0;
+                    if (bal != 0ull && lane == 0) b1 = atomicAdd(q1_count, __popcll(bal));
+                    b1 = __builtin_amdgcn_readfirstlane(b1);
+                    if (rej) slot1 = b1 + __popcll(bal & ((1ull << lane) - 1ull));
+                }
                 const bool queued = slot1 >= 0 && slot1 < q1_cap;
                 if (queued) {
                     q1[3 * slot1] = it[0];
