@@ -454,36 +454,22 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
     AO_STAMP(22);
     if (a.det.active) {
         // ---- self*self.cam: the camera on the lane's 12 pixels (detector.hpp, "Stream layout") --------------------------------
-        // the lane owns rows 0..5 of the lenslet columns q3 (Ia) and q3 + 3 (Ib); its three quads: rows 0..3 of each column, and rows
-        // 4, 5 of both columns.
+        // pixel p of the lane: p < 6 is (row p, column q3) = Ia[p], p >= 6 is (row p - 6, column q3 + 3) = Ib[p - 6]; its three
+        // quads: t = 0 rows 0..3 of column q3, t = 1 rows 0..3 of column q3 + 3, t = 2 rows 4, 5 of both columns.
         // Faint pixels (lambda < 10) are drawn here by inversion, every lane walking its 12 pixels; the bright ones (a few per
         // lenslet, ~1/5 of the frame) go through a queue in LDS and are drawn by ALL lanes of the workgroup, densely packed: as a
         // per-lane branch the rejection sampler ran for the 12 pixels of every lane, in as many rounds as the slowest lane needed.
         // The pixel loops are rolled (one copy of each sampler; the registers are picked by select chains on the loop index).
         const float rtab = recip_table_lane();
         const uint32_t px0 = (uint32_t)((li * 6) * R + lj * 6 + q3);           // frame index of the lane's pixel (row 0, column q3)
-        // The lanes of a wave walk their pixels together, and a wave pays for the faint sampler AND the bright one wherever it holds
-        // both kinds: so every lane takes its OUTER column first (q3 = 0: column 0; q3 = 2: column 5 -- its two columns swapped)
-        // and its inner one second.  Outer columns are faint in every lenslet, inner ones bright: most turns then need one
-        // sampler only.  Registers p < 6 hold the lane's first column (rows 0..5), p >= 6 its second; the streams are untouched
-        // (quads and pixels are named by their place in the frame).
-        const bool swp = q3 == 2;
-        const uint32_t px_first = px0 + (swp ? 3u : 0u), px_second = px0 + (swp ? 0u : 3u);
-        auto pix_of = [&](int p) { return (p < 6 ? px_first : px_second) + (uint32_t)((p < 6 ? p : p - 6) * R); };
-        auto quad_of = [&](int t) { return t == 0 ? px_first : (t == 1 ? px_second : px0 + (uint32_t)(4 * R)); };
-        // quad t = 2 holds rows 4, 5 of column q3 in its slots 0, 1 and of column q3 + 3 in slots 2, 3: a lane with swapped columns
-        // finds its register p = 4, 5 (first column) in slots 2, 3
-        auto slot_word = [&](const uint32_t (&o)[4], int t, int sl4) {
-            const uint32_t wa = word_of(o, sl4), wb = word_of(o, sl4 ^ 2);
-            return (t == 2 && swp) ? wb : wa;
-        };
+        auto pix_of = [&](int p) { return px0 + (uint32_t)((p < 6 ? p : p - 6) * R + (p < 6 ? 0 : 3)); };
         auto pixel_of_slot = [](int t, int sl4) { return t == 0 ? sl4 : (t == 1 ? 6 + sl4 : (sl4 < 2 ? 4 + sl4 : 8 + sl4)); };
         // the lane's 12 pixels as ONE vector register group indexed by the (wave-uniform) loop counter: v_movrel-class register
         // indexing.  (float[6] arrays picked by select chains were turned back into an indexed array in scratch memory.)
         typedef float f32x16s __attribute__((ext_vector_type(16)));
         f32x16s pxv;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) { pxv[i] = swp ? Ib[i] : Ia[i]; pxv[6 + i] = swp ? Ia[i] : Ib[i]; }
+        for (int i = 0; i < 6; ++i) { pxv[i] = Ia[i]; pxv[6 + i] = Ib[i]; }
 #pragma unroll
         for (int i = 12; i < 16; ++i) pxv[i] = 0.f;
         auto pick = [&](int p) { return pxv[p]; };
@@ -505,7 +491,7 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
         if (a.det.photon_noise) {
 #pragma unroll 1
             for (int t = 0; t < 3; ++t) {
-                const uint32_t qid = quad_of(t);
+                const uint32_t qid = px0 + (t == 1 ? 3u : (t == 2 ? (uint32_t)(4 * R) : 0u));
                 uint32_t o[4], o2[4];
                 quad_bits(qid, (uint32_t)e, a.det, kDrawPhoton, o);
                 quad_bits(qid, (uint32_t)e, a.det, kDrawPhoton2, o2);
@@ -514,8 +500,7 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
                     const int pa = pixel_of_slot(t, 2 * h), pb = pixel_of_slot(t, 2 * h + 1);
                     const float va = pick(pa), vb = pick(pb);
                     const bool fa_ = !ok || !(va >= kPtrsFrom), fb_ = !ok || !(vb >= kPtrsFrom);
-                    const uint32_t wua = slot_word(o, t, 2 * h), wub = slot_word(o, t, 2 * h + 1);
-                    const uint32_t wva = slot_word(o2, t, 2 * h), wvb = slot_word(o2, t, 2 * h + 1);
+                    const uint32_t wua = word_of(o, 2 * h), wub = word_of(o, 2 * h + 1), wva = word_of(o2, 2 * h), wvb = word_of(o2, 2 * h + 1);
                     const f32x2d lam2 = {fa_ && ok ? fmaxf(va, 0.f) : 0.f, fb_ && ok ? fmaxf(vb, 0.f) : 0.f};
                     f32x2d k2 = {0.f, 0.f};
                     if (__any(lam2.x > 0.f || lam2.y > 0.f)) k2 = poisson_inversion2(lam2, f32x2d{u01(wua), u01(wub)}, rtab);
@@ -561,11 +546,11 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
                 for (int p = 0; p < 12; ++p)
                     if (spilled >> p & 1u) {
                         const int t = p < 4 ? 0 : (p >= 6 && p < 10 ? 1 : 2), sl4 = t == 0 ? p : (t == 1 ? p - 6 : (p < 6 ? p - 4 : p - 8));
-                        const uint32_t qid = quad_of(t);
+                        const uint32_t qid = px0 + (t == 1 ? 3u : (t == 2 ? (uint32_t)(4 * R) : 0u));
                         uint32_t o[4], o2[4];
                         quad_bits(qid, (uint32_t)e, a.det, kDrawPhoton, o);
                         quad_bits(qid, (uint32_t)e, a.det, kDrawPhoton2, o2);
-                        put(p, poisson_ptrs(pick(p), slot_word(o, t, sl4), slot_word(o2, t, sl4), pix_of(p), (uint32_t)e, a.det));
+                        put(p, poisson_ptrs(pick(p), word_of(o, sl4), word_of(o2, sl4), pix_of(p), (uint32_t)e, a.det));
                     }
             }
             AO_STAMP(23);
@@ -630,13 +615,13 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
         if (has_dark || has_read || a.det.qe != 1.f || a.det.gain != 1.f || a.det.fwc > 0.f || a.det.bits > 0) {
 #pragma unroll 1
             for (int t = 0; t < 3; ++t) {
-                const uint32_t qid = quad_of(t);
+                const uint32_t qid = px0 + (t == 1 ? 3u : (t == 2 ? (uint32_t)(4 * R) : 0u));
                 f32x4d dark = {0.f, 0.f, 0.f, 0.f}, nrm = {0.f, 0.f, 0.f, 0.f};
                 if (has_dark) {
                     uint32_t o[4];
                     quad_bits(qid, (uint32_t)e, a.det, kDrawDark, o);
 #pragma unroll 1
-                    for (int sl4 = 0; sl4 < 4; ++sl4) dark[sl4] = poisson_inversion(a.det.dark_e, u01(slot_word(o, t, sl4)), rtab);
+                    for (int sl4 = 0; sl4 < 4; ++sl4) dark[sl4] = poisson_inversion(a.det.dark_e, u01(word_of(o, sl4)), rtab);
                 }
                 if (has_read) {
                     uint32_t o[4];
@@ -646,13 +631,12 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
 #pragma unroll 1
                 for (int sl4 = 0; sl4 < 4; ++sl4) {
                     const int p = pixel_of_slot(t, sl4);
-                    const float nr = (t == 2 && swp) ? nrm[sl4 ^ 2] : nrm[sl4];       // (dark[] was drawn with the lane's own slot mapping)
-                    put(p, detector_finish(pick(p), a.det, dark[sl4], nr));
+                    put(p, detector_finish(pick(p), a.det, dark[sl4], nrm[sl4]));
                 }
             }
         }
 #pragma unroll
-        for (int i = 0; i < 6; ++i) { Ia[i] = swp ? pxv[6 + i] : pxv[i]; Ib[i] = swp ? pxv[i] : pxv[6 + i]; }
+        for (int i = 0; i < 6; ++i) { Ia[i] = pxv[i]; Ib[i] = pxv[6 + i]; }
     }
     if (ok) {
         float* fr = a.frame + pix0 + (size_t)(li * 6) * R + lj * 6 + q3;
