@@ -407,7 +407,10 @@ class BatchedAOEnv:
         ``camera``: the WFS detector the env ends set_params with -- "papyrus" (default): ``wfs.cam.photonNoise = True``
         (OOPAOEnv.py:379); "razor": the Razor env's CMOS camera (QE 0.56, FWC 1e4, 10-bit ADC, dark current 5 e-/s set before the
         calibration, photon noise and 14 e- read-out noise after it, OOPAOEnvRazor.py:243-250, 332-333); "ideal": no noise (the
-        parity configuration: the reference's noisy frames are wall-clock seeded, Detector.py:127-130)."""
+        parity configuration: the reference's noisy frames are wall-clock seeded, Detector.py:127-130).  The calibration itself always
+        sees ideal spot intensities, as in the reference: the WFS constructor measures its reference slopes before the camera is
+        configured, and the interaction-matrix pokes go through the Shack-Hartmann's multi-wave-front branch, which computes the
+        centroids from the intensities without passing them through the detector (OOPAO/ShackHartmann.py:605-672)."""
         if camera not in CAMERAS:
             raise ValueError(f"camera must be one of {sorted(CAMERAS)}")
         self.camera = camera
@@ -496,7 +499,7 @@ class BatchedAOEnv:
         self.wfs.cam.configure(**post)                              # OOPAOEnv.py:379 / OOPAOEnvRazor.py:332-333
         return self
 
-    def _make_shard(self, n_env, dtype, n_layer, max_group, cam_pre=False) -> Shard:
+    def _make_shard(self, n_env, dtype, n_layer, max_group) -> Shard:
         p, at, dmt = self.param, self._atm_tables, self._dm_tables
         valid_idx = self._wfs_valid_idx
         cfg = dict(dtype=L.F32 if dtype == "f32" else L.F64, n_env=n_env, resolution=self.R, n_layer=n_layer,
@@ -512,17 +515,6 @@ class BatchedAOEnv:
             cfg.update(wfs_type=L.WFS_PYRAMID, pyr_n_res=pt.nRes, pyr_n_theta=self._wfs_n_theta,
                        pyr_centering=int(pt.psf_centering), pyr_norm_valid=pt.norm_valid, pyr_q_lo=pt.q_lo, pyr_q_hi=pt.q_hi)
         sh = Shard(cfg, self.device_index)
-        pre = CAMERAS[getattr(self, "camera", "ideal")][0]
-        if pre and cam_pre:
-            # the interaction-matrix pokes see the camera as it is set at that point of set_params (the WFS constructor measured its
-            # reference slopes and units before, with the default camera): InteractionMatrix(noise='off') clears photon / read-out
-            # noise only (OOPAO/calibration/InteractionMatrix.py:37-40); QE, full well, ADC and the dark shot noise stay.  Every
-            # calibration shard draws its dark noise from its own stream.
-            self._cal_count = getattr(self, "_cal_count", 0) + 1
-            d = L.AoDetector(photon_noise=0, bits=int(pre.get("bits") or 0), emccd=int(pre.get("sensor") == "EMCCD"), env_index_offset=0,
-                             qe=float(pre.get("QE", 1)), dark_electrons=float(pre.get("darkCurrent", 0)) * float(self.param.samplingTime),
-                             fwc=float(pre.get("FWC") or 0), gain=1.0, readout_noise=0.0, seed=0xCA11B000 + self._cal_count)
-            L.check(sh.lib.aoenv_set_detector(sh.h, C.byref(d), None))
         sh.upload(L.C_PUPIL, self.pupil.astype(np.uint8))
         if self._dm_separable:
             sh.upload(L.C_DM_GX, dmt.gx)
@@ -618,7 +610,7 @@ class BatchedAOEnv:
             spans += [(a0, min(batch, lo + n_dm - a0)) for a0 in range(lo, lo + n_dm, batch)]
             lo += n_dm
         for a0, n in spans:
-            cal = self._make_shard(n, "f64", n_layer=0, max_group=n_meas, cam_pre=True)
+            cal = self._make_shard(n, "f64", n_layer=0, max_group=n_meas)
             try:
                 cal.upload(L.C_SH_REF, ref)
                 cal.upload(L.C_WFS_UNITS, np.array([units]))

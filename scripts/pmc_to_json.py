@@ -46,13 +46,23 @@ for k, v in sorted(agg.items()):
 out = {"note": note or "rocprofv3 --pmc passes of `python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras` (scripts/pmc_collect.sh); "
        "counter values averaged per launch; hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE correction)",
        "n_envs": n_envs, "camera": camera, "kernels": kernels}
-# MFMA utilisation of the kernels that use the matrix cores: busy cycles of the MFMA pipe over the busy cycles of the shader engines
+# MFMA utilisation of the kernels that use the matrix cores.  SQ_INSTS_VALU_MFMA_MOPS_F32 counts executed matrix work in units of
+# 512 flops (checked on the step kernel: 480 v_mfma_f32_16x16x4_f32 of 2048 flops per env = 983 k flops x 256 envs / 491520 MOPS);
+# achieved = that / the kernel's average duration in the kernel trace of the same command; peak 157.3 TFLOP/s (f32-input MFMA).
+# SQ_VALU_MFMA_BUSY_CYCLES / (duration x 2.4 GHz x 1024 SIMDs) is the same figure seen from the pipe.
+dur = {}
+if stats:
+    for r in csv.DictReader(open(stats[0])):
+        dur[short(r["Name"])] = float(r["AverageNs"])
 mf = {}
 for k, e in kernels.items():
     c = e["counters_per_launch"]
-    if c.get("SQ_VALU_MFMA_BUSY_CYCLES") and c.get("SQ_BUSY_CYCLES"):
-        mf[k] = {"mfma_busy_cycles": c["SQ_VALU_MFMA_BUSY_CYCLES"], "sq_busy_cycles": c["SQ_BUSY_CYCLES"],
-                 "mfma_busy_frac": c["SQ_VALU_MFMA_BUSY_CYCLES"] / c["SQ_BUSY_CYCLES"], "mfma_mops_f32": c.get("SQ_INSTS_VALU_MFMA_MOPS_F32")}
+    if c.get("SQ_INSTS_VALU_MFMA_MOPS_F32") and k in dur:
+        flops = c["SQ_INSTS_VALU_MFMA_MOPS_F32"] * 512
+        mf[k] = {"mfma_flops_per_launch": flops, "avg_launch_us": dur[k] / 1e3, "achieved_tflops": flops / dur[k] / 1e3, "peak_tflops_f32": 157.3,
+                 "frac": flops / dur[k] / 1e3 / 157.3,
+                 "mfma_pipe_busy_frac": c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (dur[k] * 2.4 * 1024)}
 out["mfma"] = mf
+out["avg_launch_us"] = {k: v / 1e3 for k, v in dur.items() if k in kernels}
 json.dump(out, open(os.path.join(REPO, "profiles", f"{tag}_pmc.json"), "w"), indent=1)
 print(json.dumps({k: {a: b for a, b in v.items() if a != "counters_per_launch"} for k, v in kernels.items()}, indent=1))
