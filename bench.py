@@ -54,7 +54,8 @@ CONFIGS = {
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA = the f32 vector rate
-PMC_FILE = os.path.join(REPO, "profiles", "r02_pmc.json")   # rocprofv3 --pmc passes of this command (scripts/pmc_collect.sh)
+# rocprofv3 --pmc passes of this command (scripts/pmc_collect.sh -> scripts/pmc_to_json.py), one file per camera setting
+PMC_FILES = {"papyrus": os.path.join(REPO, "profiles", "r02_c2_pmc.json"), "ideal": os.path.join(REPO, "profiles", "r02_c2_ideal_pmc.json")}
 CAMERA_NOTE = {"papyrus": "photon (Poisson) noise on every WFS pixel: the reference env's default camera (OOPAOEnv.py:379)",
                "razor": "Razor camera: photon + dark + read-out noise, QE 0.56, FWC 1e4, 10-bit ADC (OOPAOEnvRazor.py:243-250, 332-333)",
                "ideal": "ideal detector (the parity configuration)"}
@@ -213,7 +214,7 @@ def mfma_flops_per_env_step(env):
 
 def load_pmc(n_envs, camera):
     try:
-        with open(PMC_FILE) as f:
+        with open(PMC_FILES[camera]) as f:
             d = json.load(f)
         if d.get("n_envs") == n_envs and d.get("camera") == camera:
             return d
@@ -500,7 +501,7 @@ def main():
         "mfma": {"flops_per_env_step": fl["total"], "split": {k: v for k, v in fl.items() if k != "total"},
                  "achieved_tflops": fl["total"] * n_local / (dt / K) / 1e12, "peak_tflops_f32": MFMA_F32_PEAK_TFLOPS,
                  "frac": fl["total"] * n_local / (dt / K) / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                 "pmc": None if pmc is None else pmc.get("mfma")},
+                 "pmc": None if pmc is None else pmc.get("mfma", {}).get("env_step")},
         "kernels": per_kernel,
         "mean_strehl_last_step": strehl,
         "mean_episode_return": float(gathered["returns"].mean()),

@@ -35,6 +35,13 @@ namespace ao { __device__ unsigned long long g_stamps[1024 * 32]; __device__ uns
 #include "sh_device.hpp"
 #include "detector.hpp"
 
+// diagnostic ablation of the camera block (scripts/diag_cam_ablate.sh): -DAO_CAM_ABLATE=<bit mask>; wrong frames, timing only
+#ifdef AO_CAM_ABLATE
+#define AO_ABL(bit) (((AO_CAM_ABLATE) >> (bit)) & 1)
+#else
+#define AO_ABL(bit) 0
+#endif
+
 namespace ao {
 
 typedef float f32x4s __attribute__((ext_vector_type(4)));
@@ -493,8 +500,13 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
             for (int t = 0; t < 3; ++t) {
                 const uint32_t qid = px0 + (t == 1 ? 3u : (t == 2 ? (uint32_t)(4 * R) : 0u));
                 uint32_t o[4], o2[4];
-                quad_bits(qid, (uint32_t)e, a.det, kDrawPhoton, o);
-                quad_bits(qid, (uint32_t)e, a.det, kDrawPhoton2, o2);
+                if (AO_ABL(0)) {
+#pragma unroll
+                    for (int z = 0; z < 4; ++z) { o[z] = (qid + z) * 2654435761u + a.det.frame_counter; o2[z] = o[z] * 40503u + z; }
+                } else {
+                    quad_bits(qid, (uint32_t)e, a.det, kDrawPhoton, o);
+                    quad_bits(qid, (uint32_t)e, a.det, kDrawPhoton2, o2);
+                }
 #pragma unroll 1
                 for (int h = 0; h < 2; ++h) {                                 // two pixels per turn: the inversion runs on packed pairs
                     const int pa = pixel_of_slot(t, 2 * h), pb = pixel_of_slot(t, 2 * h + 1);
@@ -503,9 +515,9 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
                     const uint32_t wua = word_of(o, 2 * h), wub = word_of(o, 2 * h + 1), wva = word_of(o2, 2 * h), wvb = word_of(o2, 2 * h + 1);
                     const f32x2d lam2 = {fa_ && ok ? fmaxf(va, 0.f) : 0.f, fb_ && ok ? fmaxf(vb, 0.f) : 0.f};
                     f32x2d k2 = {0.f, 0.f};
-                    if (__any(lam2.x > 0.f || lam2.y > 0.f)) k2 = poisson_inversion2(lam2, f32x2d{u01(wua), u01(wub)}, rtab);
+                    if (!AO_ABL(1) && __any(lam2.x > 0.f || lam2.y > 0.f)) k2 = poisson_inversion2(lam2, f32x2d{u01(wua), u01(wub)}, rtab);
                     // bright pixels: proposal + squeeze of the first PTRS round, here and now (no logarithm)
-                    if (__any(!fa_ || !fb_)) {
+                    if (!AO_ABL(2) && __any(!fa_ || !fb_)) {
 #pragma unroll
                         for (int z = 0; z < 2; ++z) {
                             const bool faint = z ? fb_ : fa_;
@@ -517,7 +529,7 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
                             float outv = faint ? (z ? k2.y : k2.x) : kb;
                             // one LDS atomic per wave and pixel position, not one per undecided pixel (2500 adds to one
                             // address per frame were a queue of their own): ballot + popcount hand out the wave's indices
-                            const bool undecided = !faint && !sq;
+                            const bool undecided = !AO_ABL(3) && !faint && !sq;
                             const unsigned long long bal = __ballot(undecided);
                             int idx_base = 0;
                             if (bal != 0ull && lane == 0) idx_base = atomicAdd(q_count, __popcll(bal));
@@ -556,7 +568,7 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
             AO_STAMP(23);
             lds_barrier();                                                    // every wave has its spots: E0 is free; Q0 is complete
             AO_STAMP(6);
-            const int n_q0 = min(*q_count, q0_cap);
+            const int n_q0 = AO_ABL(4) ? 0 : min(*q_count, q0_cap);
             // pass 1: round 0's full test, one entry per lane; accepted -> res, rejected -> Q1 (or, Q1 full, finished on the spot)
             for (int i0 = 64 * w; i0 < n_q0; i0 += 1024) {
                 const int i = i0 + lane;

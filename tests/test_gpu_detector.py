@@ -72,6 +72,37 @@ def test_photon_noise_is_poisson_and_reproducible():
     env.close()
 
 
+def test_photon_counts_follow_the_poisson_law_in_both_samplers():
+    """Distribution test of the photon draw, per brightness class: for X ~ Poisson(lam) and V ~ U(0, 1) independent,
+    F(X - 1) + V p(X) is uniform on (0, 1) (randomised probability-integral transform), whatever lam each pixel has.  Pooled over
+    the pixels of a class x 256 envs x 4 frames: chi-square of a 64-bin histogram and the Kolmogorov-Smirnov distance.  Classes
+    below 10 photons are drawn by lock-step inversion, from 10 on by PTRS (squeeze in registers, queue passes): both are exact
+    samplers, so no approximation error is allowed for."""
+    from scipy import stats
+    env = _env(256)
+    ideal = _frames(env)[0]
+    env.wfs.cam.photonNoise = True
+    a = np.stack([_frames(env) for _ in range(4)])               # [4, 256, cam, cam]
+    env.close()
+    rs = np.random.RandomState(3)
+    tested = []
+    for lo, hi in ((0.02, 1.0), (1.0, 10.0), (10.0, 30.0), (30.0, 1e9)):
+        sel = (ideal >= lo) & (ideal < hi)
+        if sel.sum() < 8:
+            continue
+        lam = ideal[sel]
+        x = a[:, :, sel].reshape(-1, lam.size)
+        u = stats.poisson.cdf(x - 1, lam) + rs.uniform(size=x.shape) * stats.poisson.pmf(x, lam)
+        n = u.size
+        h = np.histogram(u, bins=64, range=(0, 1))[0]
+        chi2 = float(((h - n / 64) ** 2 / (n / 64)).sum())
+        ks = float(stats.kstest(u.ravel(), "uniform").statistic) * np.sqrt(n)
+        assert chi2 < stats.chi2.ppf(1 - 1e-6, 63), (lo, hi, chi2)          # 63 dof: 99.9999 % point = 137
+        assert ks < 2.2, (lo, hi, ks)                                       # P(sqrt(n) D > 2.2) = 1.2e-4
+        tested.append((lo, hi, int(sel.sum()), chi2, ks))
+    assert any(hi <= 10 for _, hi, *_ in tested) and any(lo >= 10 for lo, *_ in tested), tested
+
+
 def test_razor_camera_moments_match_oracle():
     """Razor settings (MAIN/OOPAOEnv/OOPAOEnvRazor.py:243-250, 333): photon + dark + read-out noise, QE, FWC, 10 bits."""
     from oracle import ao_oracle as O             # checker only
