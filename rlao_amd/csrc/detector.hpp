@@ -107,13 +107,13 @@ __device__ inline f32x2d poisson_inversion2(f32x2d lam, f32x2d u, float rtab) {
 }
 
 // log(k!) for integer-valued k >= 0.
-// (lgammaf costs ~10x more instructions, and the PTRS acceptance test below runs for every bright pixel of every frame.)
+// (lgammaf costs ~10x more instructions, and the PTRS acceptance test below runs for every undecided bright pixel of every frame.)
 __device__ inline float log_factorial(float k) {
-    // k >= 4: Stirling's series with three correction terms, |error| < 2e-8;  k = 0..3 from a 4-entry select
+    // k >= 4: Stirling's series with three correction terms, |error| < 2e-8, as (k + 1/2) log k - k + log sqrt(2 pi) + ...: one
+    // logarithm and one reciprocal (transcendentals issue at a quarter of the rate);  k = 0..3 from a 4-entry select
     const float kk = fmaxf(k, 4.f);
     const float r = __builtin_amdgcn_rcpf(kk), r2 = r * r;
-    const float st = kk * __logf(kk) - kk + 0.5f * __logf(6.283185307179586f * kk) +
-                     r * (0.0833333333f + r2 * (-0.00277777778f + r2 * 0.000793650794f));
+    const float st = (kk + 0.5f) * __logf(kk) - kk + 0.918938533f + r * (0.0833333333f + r2 * (-0.00277777778f + r2 * 0.000793650794f));
     const float small = k < 2.f ? 0.f : (k < 3.f ? 0.693147181f : 1.791759469f);
     return k < 4.f ? small : st;
 }
@@ -121,35 +121,35 @@ __device__ inline float log_factorial(float k) {
 // Poisson(lam), lam >= kPtrsFrom: Hoermann's PTRS (exact; the algorithm NumPy's legacy generator uses from lam = 10).
 // Round 0 takes its two uniforms from the pixel's words of the quad draws kDrawPhoton (U) and kDrawPhoton2 (V); a pixel that
 // round 0 rejects (~8 % of them) goes on with a stream of its own: call j gives the uniforms of rounds 1 + 2j, 2 + 2j.
-struct PtrsConst { float b, a, vr, lam; };
+struct PtrsConst { float b, a, lam; };
 __device__ inline PtrsConst ptrs_const(float lam) {
-    // (1-ulp hardware reciprocals / square root: an IEEE division expands to ~10 instructions, and the constants of the
-    //  hat function do not need the last bit)
+    // (1-ulp hardware square root: the constants of the hat function do not need the last bit)
     PtrsConst c;
     c.lam = lam;
     c.b = 0.931f + 2.53f * __builtin_amdgcn_sqrtf(lam);
     c.a = -0.059f + 0.02483f * c.b;
-    c.vr = 0.9277f - 3.6224f * __builtin_amdgcn_rcpf(c.b - 2.f);
     return c;
 }
-// the cheap part of a round: proposal k and the squeeze (accepts ~86 % of the proposals without a logarithm)
+// the cheap part of a round: proposal k and the squeeze (accepts 35 % of the proposals at 10 photons, 67 % at 100, without a
+// logarithm).  V <= vr = 0.9277 - 3.6224 / (b - 2) is tested as (0.9277 - V)(b - 2) >= 3.6224: no division (b > 8.9).
 __device__ inline bool ptrs_squeeze(const PtrsConst& c, uint32_t wu, uint32_t wv, float* kf, float* us_out, float* v_out) {
     const float U = u01(wu) - 0.5f, V = u01(wv);
     const float us = 0.5f - fabsf(U);
     *kf = floorf((2.f * c.a * __builtin_amdgcn_rcpf(us) + c.b) * U + c.lam + 0.43f);
     *us_out = us;
     *v_out = V;
-    return us >= 0.07f && V <= c.vr;
+    return us >= 0.07f && (0.9277f - V) * (c.b - 2.f) >= 3.6224f;
 }
-// the full acceptance test of a proposal the squeeze did not accept
-__device__ inline bool ptrs_full(const PtrsConst& c, float kf, float us, float V, float loglam, float log_invalpha) {
+// the full acceptance test of a proposal the squeeze did not accept:
+//   log V + log invalpha - log(a / us^2 + b) <= -lam + k log lam - log k!      with the left side as ONE logarithm
+struct PtrsLogs { float loglam, invalpha; };
+__device__ inline PtrsLogs ptrs_logs(const PtrsConst& c) {
+    return {__logf(c.lam), 1.1239f + 1.1328f * __builtin_amdgcn_rcpf(c.b - 3.4f)};
+}
+__device__ inline bool ptrs_full(const PtrsConst& c, float kf, float us, float V, const PtrsLogs& g) {
     if (kf < 0.f || (us < 0.013f && V > us)) return false;
     const float rus = __builtin_amdgcn_rcpf(us);
-    return __logf(V) + log_invalpha - __logf(c.a * rus * rus + c.b) <= -c.lam + kf * loglam - log_factorial(kf);
-}
-struct PtrsLogs { float loglam, log_invalpha; };
-__device__ inline PtrsLogs ptrs_logs(const PtrsConst& c) {
-    return {__logf(c.lam), __logf(1.1239f + 1.1328f * __builtin_amdgcn_rcpf(c.b - 3.4f))};
+    return __logf(V * g.invalpha * __builtin_amdgcn_rcpf(c.a * rus * rus + c.b)) <= -c.lam + kf * g.loglam - log_factorial(kf);
 }
 // rounds 1, 2, ... of a pixel whose round 0 was rejected: its own stream, until accepted.  Whole waves call this together.
 __device__ inline float poisson_ptrs_rounds(const PtrsConst& c, const PtrsLogs& g, bool done, float result, uint32_t pixel, uint32_t env,
@@ -161,8 +161,9 @@ __device__ inline float poisson_ptrs_rounds(const PtrsConst& c, const PtrsLogs& 
         philox4x32(pixel, env + d.env_offset, d.frame_counter, kDrawPixelStream + call, d.seed_lo, d.seed_hi, o);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
+            if (h == 1 && !__any(!done)) break;                  // (the first round of a call settles ~87 % of the lanes)
             bool acc = ptrs_squeeze(c, o[2 * h], o[2 * h + 1], &kf, &us, &V);
-            if (__any(!done && !acc)) acc = acc || ptrs_full(c, kf, us, V, g.loglam, g.log_invalpha);
+            if (__any(!done && !acc)) acc = acc || ptrs_full(c, kf, us, V, g);
             if (!done && acc) { result = kf; done = true; }
         }
     }
@@ -173,7 +174,7 @@ __device__ inline float poisson_ptrs(float lam, uint32_t wu, uint32_t wv, uint32
     const PtrsLogs g = ptrs_logs(c);
     float kf, us, V;
     bool done = ptrs_squeeze(c, wu, wv, &kf, &us, &V);
-    if (__any(!done)) done = done || ptrs_full(c, kf, us, V, g.loglam, g.log_invalpha);      // (everyone evaluates it: one wave)
+    if (__any(!done)) done = done || ptrs_full(c, kf, us, V, g);      // (everyone evaluates it: one wave)
     return poisson_ptrs_rounds(c, g, done, done ? kf : floorf(lam + 0.5f), pixel, env, d);
 }
 

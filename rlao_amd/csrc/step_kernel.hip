@@ -106,9 +106,8 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
     __shared__ double red[4][16];
     __shared__ double red_tail[16];
     __shared__ float red_mx[16];
-    __shared__ int q_count_s[2];                                 // stage B camera: entries of the queues Q0 and Q1
-    int* q_count = &q_count_s[0];
-    int* q1_count = &q_count_s[1];
+    __shared__ int q_count_s[17];                                // stage B camera: entries of the 16 wave segments of Q0, of Q1
+    int* q1_count = &q_count_s[16];
 
     const int e = blockIdx.x;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
@@ -150,7 +149,7 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
     for (int i = tid; i < 2 * PR * SS; i += 1024) s1[i] = 0.f;
     if (tid < n_sub * n_sub) slot_s[tid] = slot_v;
     for (int i = tid + 1024; i < n_sub * n_sub; i += 1024) slot_s[i] = a.slot_of[i];
-    if (tid < 2) q_count_s[tid] = 0;
+    if (tid < 17) q_count_s[tid] = 0;
     lds_barrier();
     if (has_act) cimg[act_px] = act_c;
     float breg[2][KS];
@@ -494,7 +493,11 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
         float* res = lds + L.e0;
         float* q1 = lds + L.e0 + q0_cap;                                       // 3 words per entry
         const int q1_cap = (L.total - L.e0 - q0_cap) / 3;
-        uint32_t pending = 0, spilled = 0;                                   // spilled: bright, undecided, and Q0 was full
+        uint32_t pending = 0, spilled = 0;                                   // spilled: bright, undecided, and the wave's part of Q0 was full
+        // Q0 is cut into 16 wave-private segments: a wave hands out its indices from a counter of its own (a wave-uniform
+        // register) -- a shared counter was one LDS atomic round trip, with the wave waiting on it, per pixel position.
+        const int seg_cap = q0_cap / 16, seg0 = w * seg_cap;
+        int seg_n = 0;
         if (a.det.photon_noise) {
 #pragma unroll 1
             for (int t = 0; t < 3; ++t) {
@@ -507,52 +510,60 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
                     quad_bits(qid, (uint32_t)e, a.det, kDrawPhoton, o);
                     quad_bits(qid, (uint32_t)e, a.det, kDrawPhoton2, o2);
                 }
-#pragma unroll 1
-                for (int h = 0; h < 2; ++h) {                                 // two pixels per turn: the inversion runs on packed pairs
-                    const int pa = pixel_of_slot(t, 2 * h), pb = pixel_of_slot(t, 2 * h + 1);
-                    const float va = pick(pa), vb = pick(pb);
-                    const bool fa_ = !ok || !(va >= kPtrsFrom), fb_ = !ok || !(vb >= kPtrsFrom);
-                    const uint32_t wua = word_of(o, 2 * h), wub = word_of(o, 2 * h + 1), wva = word_of(o2, 2 * h), wvb = word_of(o2, 2 * h + 1);
-                    const f32x2d lam2 = {fa_ && ok ? fmaxf(va, 0.f) : 0.f, fb_ && ok ? fmaxf(vb, 0.f) : 0.f};
-                    f32x2d k2 = {0.f, 0.f};
-                    if (!AO_ABL(1) && __any(lam2.x > 0.f || lam2.y > 0.f)) k2 = poisson_inversion2(lam2, f32x2d{u01(wua), u01(wub)}, rtab);
-                    // bright pixels: proposal + squeeze of the first PTRS round, here and now (no logarithm)
-                    if (!AO_ABL(2) && __any(!fa_ || !fb_)) {
+                int p4[4];
+                f32x4d v4, out4 = {0.f, 0.f, 0.f, 0.f};
+                bool faint[4];
 #pragma unroll
-                        for (int z = 0; z < 2; ++z) {
-                            const bool faint = z ? fb_ : fa_;
-                            const float v = z ? vb : va;
-                            const uint32_t wu = z ? wub : wua, wv = z ? wvb : wva;
-                            const int p = z ? pb : pa;
-                            float kb, us, V;
-                            const bool sq = ptrs_squeeze(ptrs_const(faint ? kPtrsFrom : v), wu, wv, &kb, &us, &V);
-                            float outv = faint ? (z ? k2.y : k2.x) : kb;
-                            // one LDS atomic per wave and pixel position, not one per undecided pixel (2500 adds to one
-                            // address per frame were a queue of their own): ballot + popcount hand out the wave's indices
-                            const bool undecided = !AO_ABL(3) && !faint && !sq;
-                            const unsigned long long bal = __ballot(undecided);
-                            int idx_base = 0;
-                            if (bal != 0ull && lane == 0) idx_base = atomicAdd(q_count, __popcll(bal));
-                            idx_base = __builtin_amdgcn_readfirstlane(idx_base);
-                            if (undecided) {
-                                const int idx = idx_base + __popcll(bal & ((1ull << lane) - 1ull));
-                                if (idx < q0_cap) {
-                                    q0[idx] = f32x4s{v, __uint_as_float(pix_of(p)), __uint_as_float(wu), __uint_as_float(wv)};
-                                    outv = __int_as_float(idx);
-                                    pending |= 1u << p;
+                for (int sl = 0; sl < 4; ++sl) {
+                    p4[sl] = pixel_of_slot(t, sl);
+                    v4[sl] = pick(p4[sl]);
+                    faint[sl] = !ok || !(v4[sl] >= kPtrsFrom);
+                }
+                // faint pixels: inversion, two pixels per turn as packed pairs
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f32x2d lam2 = {faint[2 * h] && ok ? fmaxf(v4[2 * h], 0.f) : 0.f, faint[2 * h + 1] && ok ? fmaxf(v4[2 * h + 1], 0.f) : 0.f};
+                    f32x2d k2 = {0.f, 0.f};
+                    if (!AO_ABL(1) && __any(lam2.x > 0.f || lam2.y > 0.f)) k2 = poisson_inversion2(lam2, f32x2d{u01(o[2 * h]), u01(o[2 * h + 1])}, rtab);
+                    out4[2 * h] = k2.x;
+                    out4[2 * h + 1] = k2.y;
+                }
+                // bright pixels: proposal + squeeze of the first PTRS round for the quad's four pixels at once (no logarithm; four
+                // independent dependency chains: a single one left the vector unit waiting on its square root and reciprocals)
+                if (!AO_ABL(2) && __any(!faint[0] || !faint[1] || !faint[2] || !faint[3])) {
+                    bool und[4];
+                    unsigned long long bal[4];
+#pragma unroll
+                    for (int sl = 0; sl < 4; ++sl) {
+                        float kb, us, V;
+                        const bool sq = ptrs_squeeze(ptrs_const(faint[sl] ? kPtrsFrom : v4[sl]), o[sl], o2[sl], &kb, &us, &V);
+                        und[sl] = !AO_ABL(3) && !faint[sl] && !sq;
+                        out4[sl] = faint[sl] ? out4[sl] : kb;
+                    }
+#pragma unroll
+                    for (int sl = 0; sl < 4; ++sl) bal[sl] = __ballot(und[sl]);
+                    if ((bal[0] | bal[1] | bal[2] | bal[3]) != 0ull) {
+#pragma unroll
+                        for (int sl = 0; sl < 4; ++sl) {
+                            if (und[sl]) {
+                                const int idx = seg_n + __popcll(bal[sl] & ((1ull << lane) - 1ull));
+                                if (idx < seg_cap) {
+                                    q0[seg0 + idx] = f32x4s{v4[sl], __uint_as_float(pix_of(p4[sl])), __uint_as_float(o[sl]), __uint_as_float(o2[sl])};
+                                    out4[sl] = __int_as_float(seg0 + idx);
+                                    pending |= 1u << p4[sl];
                                 } else {
-                                    outv = v;
-                                    spilled |= 1u << p;
+                                    out4[sl] = v4[sl];
+                                    spilled |= 1u << p4[sl];
                                 }
                             }
-                            put(p, outv);
+                            seg_n += __popcll(bal[sl]);
                         }
-                    } else {
-                        put(pa, k2.x);
-                        put(pb, k2.y);
                     }
                 }
+#pragma unroll
+                for (int sl = 0; sl < 4; ++sl) put(p4[sl], out4[sl]);
             }
+            if (lane == 0) q_count_s[w] = min(seg_n, seg_cap);
             if (__any(spilled != 0)) {                                        // Q0 full (a very bright star): these lanes' own work
 #pragma unroll 1
                 for (int p = 0; p < 12; ++p)
@@ -568,35 +579,62 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
             AO_STAMP(23);
             lds_barrier();                                                    // every wave has its spots: E0 is free; Q0 is complete
             AO_STAMP(6);
-            const int n_q0 = AO_ABL(4) ? 0 : min(*q_count, q0_cap);
-            // pass 1: round 0's full test, one entry per lane; accepted -> res, rejected -> Q1 (or, Q1 full, finished on the spot)
-            for (int i0 = 64 * w; i0 < n_q0; i0 += 1024) {
-                const int i = i0 + lane;
-                const bool live = i < n_q0;
-                const f32x4s it = q0[live ? i : 0];
-                const PtrsConst c = ptrs_const(live ? it[0] : kPtrsFrom);
-                const PtrsLogs g = ptrs_logs(c);
-                float kf, us, V;
-                bool done = ptrs_squeeze(c, __float_as_uint(it[2]), __float_as_uint(it[3]), &kf, &us, &V);     // (known: not accepted)
-                done = done || ptrs_full(c, kf, us, V, g.loglam, g.log_invalpha);
-                int slot1 = -1;
-                {
-                    const bool rej = live && !done;
-                    const unsigned long long bal = __ballot(rej);
-                    int b1 = 0;
-                    if (bal != 0ull && lane == 0) b1 = atomicAdd(q1_count, __popcll(bal));
-                    b1 = __builtin_amdgcn_readfirstlane(b1);
-                    if (rej) slot1 = b1 + __popcll(bal & ((1ull << lane) - 1ull));
+            int n_q0 = 0;
+#pragma unroll
+            for (int w2 = 0; w2 < 16; ++w2) n_q0 += q_count_s[w2];
+            if (AO_ABL(4)) n_q0 = 0;
+            // pass 1: round 0's full test, TWO entries per lane and turn (two independent chains of logarithms and reciprocals);
+            // accepted -> res, rejected -> Q1 (or, Q1 full, finished on the spot)
+            for (int i0 = 64 * w; i0 < n_q0; i0 += 2048) {
+                int slot2[2];
+                bool live2[2], done2[2];
+                float kf2[2], lam2[2], pix2[2];
+#pragma unroll
+                for (int z = 0; z < 2; ++z) {
+                    const int i = i0 + 1024 * z + lane;
+                    live2[z] = i < n_q0;
+                    int slot = -1, rem = i, base = 0;                            // dense index -> (segment, entry)
+#pragma unroll
+                    for (int w2 = 0; w2 < 16; ++w2) {
+                        const int cw = q_count_s[w2];
+                        slot = (slot < 0 && rem < cw) ? base + rem : slot;
+                        rem -= cw;
+                        base += seg_cap;
+                    }
+                    slot2[z] = live2[z] ? slot : 0;
                 }
-                const bool queued = slot1 >= 0 && slot1 < q1_cap;
-                if (queued) {
-                    q1[3 * slot1] = it[0];
-                    q1[3 * slot1 + 1] = it[1];
-                    q1[3 * slot1 + 2] = __int_as_float(i);
+#pragma unroll
+                for (int z = 0; z < 2; ++z) {
+                    const f32x4s it = q0[slot2[z]];
+                    lam2[z] = live2[z] ? it[0] : kPtrsFrom;
+                    pix2[z] = it[1];
+                    const PtrsConst c = ptrs_const(lam2[z]);
+                    float us, V;
+                    ptrs_squeeze(c, __float_as_uint(it[2]), __float_as_uint(it[3]), &kf2[z], &us, &V);       // (known: not accepted)
+                    done2[z] = ptrs_full(c, kf2[z], us, V, ptrs_logs(c));
                 }
-                if (__any(live && !done && !queued))                          // Q1 full: finished here, by the lanes that drew a slot beyond it
-                    kf = poisson_ptrs_rounds(c, g, !live || done || queued, kf, __float_as_uint(it[1]), (uint32_t)e, a.det);
-                if (live && !queued) res[i] = kf;
+                const bool rejA = live2[0] && !done2[0], rejB = live2[1] && !done2[1];
+                const unsigned long long balA = __ballot(rejA), balB = __ballot(rejB);
+                int b1 = 0;
+                if ((balA | balB) != 0ull && lane == 0) b1 = atomicAdd(q1_count, __popcll(balA) + __popcll(balB));
+                b1 = __builtin_amdgcn_readfirstlane(b1);
+                const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+                for (int z = 0; z < 2; ++z) {
+                    const bool rej = z ? rejB : rejA;
+                    const int slot1 = rej ? b1 + (z ? __popcll(balA) + __popcll(balB & below) : __popcll(balA & below)) : -1;
+                    const bool queued = slot1 >= 0 && slot1 < q1_cap;
+                    if (queued) {
+                        q1[3 * slot1] = lam2[z];
+                        q1[3 * slot1 + 1] = pix2[z];
+                        q1[3 * slot1 + 2] = __int_as_float(slot2[z]);
+                    }
+                    if (__any(rej && !queued)) {                                   // Q1 full: finished here, by the lanes that drew a slot beyond it
+                        const PtrsConst c = ptrs_const(lam2[z]);
+                        kf2[z] = poisson_ptrs_rounds(c, ptrs_logs(c), !rej || queued, kf2[z], __float_as_uint(pix2[z]), (uint32_t)e, a.det);
+                    }
+                    if (live2[z] && !queued) res[slot2[z]] = kf2[z];
+                }
             }
             lds_barrier();
             AO_STAMP(12);
@@ -616,10 +654,13 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
             }
             AO_STAMP(2);
             lds_barrier();
-            if (pending) {
-#pragma unroll 1
-                for (int p = 0; p < 12; ++p)
-                    if (pending >> p & 1u) put(p, res[__float_as_int(pick(p))]);
+            // the owners pick their counts up: all 12 reads in flight at once (the register holds the entry's index)
+            if (__any(pending != 0u)) {
+                float got[12];
+#pragma unroll
+                for (int p = 0; p < 12; ++p) got[p] = res[(pending >> p & 1u) ? __float_as_int(pxv[p]) : 0];
+#pragma unroll
+                for (int p = 0; p < 12; ++p) pxv[p] = (pending >> p & 1u) ? got[p] : pxv[p];
             }
         }
         // QE, dark shot noise, saturation, gain, read-out noise, ADC: quad by quad (dark_e < kPtrsFrom: checked by the host)
