@@ -583,14 +583,14 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
 #pragma unroll
             for (int w2 = 0; w2 < 16; ++w2) n_q0 += q_count_s[w2];
             if (AO_ABL(4)) n_q0 = 0;
-            // pass 1: round 0's full test, TWO entries per lane and turn (two independent chains of logarithms and reciprocals);
+            // pass 1: round 0's full test, THREE entries per lane and turn (independent chains of logarithms and reciprocals; ~2500 entries: one turn);
             // accepted -> res, rejected -> Q1 (or, Q1 full, finished on the spot)
-            for (int i0 = 64 * w; i0 < n_q0; i0 += 2048) {
-                int slot2[2];
-                bool live2[2], done2[2];
-                float kf2[2], lam2[2], pix2[2];
+            for (int i0 = 64 * w; i0 < n_q0; i0 += 3072) {
+                int slot2[3];
+                bool live2[3], done2[3];
+                float kf2[3], lam2[3], pix2[3];
 #pragma unroll
-                for (int z = 0; z < 2; ++z) {
+                for (int z = 0; z < 3; ++z) {
                     const int i = i0 + 1024 * z + lane;
                     live2[z] = i < n_q0;
                     int slot = -1, rem = i, base = 0;                            // dense index -> (segment, entry)
@@ -604,7 +604,7 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
                     slot2[z] = live2[z] ? slot : 0;
                 }
 #pragma unroll
-                for (int z = 0; z < 2; ++z) {
+                for (int z = 0; z < 3; ++z) {
                     const f32x4s it = q0[slot2[z]];
                     lam2[z] = live2[z] ? it[0] : kPtrsFrom;
                     pix2[z] = it[1];
@@ -613,16 +613,22 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
                     ptrs_squeeze(c, __float_as_uint(it[2]), __float_as_uint(it[3]), &kf2[z], &us, &V);       // (known: not accepted)
                     done2[z] = ptrs_full(c, kf2[z], us, V, ptrs_logs(c));
                 }
-                const bool rejA = live2[0] && !done2[0], rejB = live2[1] && !done2[1];
-                const unsigned long long balA = __ballot(rejA), balB = __ballot(rejB);
+                bool rej3[3];
+                unsigned long long bal3[3];
+#pragma unroll
+                for (int z = 0; z < 3; ++z) {
+                    rej3[z] = live2[z] && !done2[z];
+                    bal3[z] = __ballot(rej3[z]);
+                }
                 int b1 = 0;
-                if ((balA | balB) != 0ull && lane == 0) b1 = atomicAdd(q1_count, __popcll(balA) + __popcll(balB));
+                if ((bal3[0] | bal3[1] | bal3[2]) != 0ull && lane == 0) b1 = atomicAdd(q1_count, __popcll(bal3[0]) + __popcll(bal3[1]) + __popcll(bal3[2]));
                 b1 = __builtin_amdgcn_readfirstlane(b1);
                 const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
-                for (int z = 0; z < 2; ++z) {
-                    const bool rej = z ? rejB : rejA;
-                    const int slot1 = rej ? b1 + (z ? __popcll(balA) + __popcll(balB & below) : __popcll(balA & below)) : -1;
+                for (int z = 0; z < 3; ++z) {
+                    const bool rej = rej3[z];
+                    const int slot1 = rej ? b1 + __popcll(bal3[z] & below) : -1;
+                    b1 += __popcll(bal3[z]);
                     const bool queued = slot1 >= 0 && slot1 < q1_cap;
                     if (queued) {
                         q1[3 * slot1] = lam2[z];
