@@ -477,6 +477,16 @@ def main():
         extras["step_api"] = {"us_per_call_host": 1e6 * t_host / n_api, "us_per_step": 1e6 * t_all / n_api,
                               "value": n_total * n_api / t_all, "unit": "env-steps/s",
                               "note": "env.step(i, 0.5 * obs) from Python, 256 envs, frame returned; host time = until the call returns"}
+        # every env its own wind (a trainer that draws the wind per run): per-env clocks on the device, the ring kernels on every
+        # step.  LAST: the shard keeps its per-env clocks from here on.
+        rs = np.random.RandomState(11)
+        nl = env.param.nLayer
+        env.set_wind_per_env(rs.uniform(5.0, 15.0, size=(n_local, nl)), rs.uniform(0.0, 360.0, size=(n_local, nl)), reset=True)
+        env.run_integrator(W, 10)
+        t3 = timer.regions(lambda r: env.run_integrator(W + (r % 8) * K, K), args.min_seconds / 3)
+        s3 = stats(t3)
+        extras["per_env_wind"] = {"value": n_total * K / s3["median"], "unit": "env-steps/s", "ms_per_step": 1e3 * s3["median"] / K,
+                                  "repeats": len(t3), "note": "every env its own wind: 5-15 m/s, any direction (aoenv_set_wind_env); same camera as the headline"}
     if rank != 0:
         return
     pmc = load_pmc(n_local, camera)

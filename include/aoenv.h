@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define AOENV_ABI_VERSION 4
+#define AOENV_ABI_VERSION 5
 
 enum { AOENV_F32 = 0, AOENV_F64 = 1 };
 enum { AOENV_WFS_SH = 0, AOENV_WFS_PYRAMID = 1 };
@@ -139,6 +139,18 @@ int aoenv_upload(AoEnv* env, int kind, const void* h_data, size_t bytes);
  * h_ratio is [n_layer][2] float64, shared by all envs of the shard.  `reset_buff` != 0 also clears the
  * sub-pixel accumulator (what notDoneOnce does after generateNewPhaseScreen). */
 int aoenv_set_wind(AoEnv* env, const double* h_ratio, int reset_buff);
+
+/* The same setters when every env has its OWN wind (a trainer that draws wind speed / direction per run, e.g.
+ * MAIN/integrator_oopao_razor.py:41-44, batched): h_ratio is [n_layer][n_env][2] float64, |ratio| < 1 pixel per frame.
+ * The shard switches to per-env clocks for good: accumulators, torus origins and warp taps of every (env, layer) live on
+ * the device and are advanced there, by the same arithmetic as the shared host clock (an env stepped by its own clock is
+ * bit-identical to a shard stepped with that wind); on every step one launch per layer advances the clocks and prepares the
+ * ring operands of the envs that cross a pixel, and the ring GEMM runs over the whole shard.  aoenv_set_wind keeps working
+ * afterwards (the same wind for every env); new screens reset accumulators and origins as for the shared clock.
+ * Clock state for checkpoints: h_clock [n_layer][n_env][4] float64 = {ratio x, ratio y, buff x, buff y}. */
+int aoenv_set_wind_env(AoEnv* env, const double* h_ratio, int reset_buff, void* stream);
+int aoenv_get_clock_env(AoEnv* env, double* h_clock);
+int aoenv_set_clock_env(AoEnv* env, const double* h_clock);
 
 /* Replaces: atm.generateNewPhaseScreen(seed) (OOPAO/Atmosphere.py:560-592) for every env of the shard.
  *   h_screens [n_env][n_layer][N*N] float64: the new layer.phase screens (rad @ 500 nm), or NULL to keep

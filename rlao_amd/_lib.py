@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AOENV_LIB") or os.path.join(_HERE, "csrc", "libaoenv.so")   # AOENV_LIB: A/B kernel builds
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 F32, F64 = 0, 1
 WFS_SH, WFS_PYRAMID = 0, 1
 
@@ -65,6 +65,9 @@ EXPORTS = {
     "aoenv_buffer": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "aoenv_download": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "aoenv_upload_state": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "aoenv_set_wind_env": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "aoenv_get_clock_env": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "aoenv_set_clock_env": (C.c_int, [C.c_void_p, C.c_void_p]),
     "aoenv_get_buff": (C.c_int, [C.c_void_p, C.c_void_p]),
     "aoenv_set_buff": (C.c_int, [C.c_void_p, C.c_void_p]),
     "aoenv_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),

@@ -184,6 +184,52 @@ int launch_ring_prepare(const T* map, T* zx, const int* inner_idx, const uint32_
     return 0;
 }
 
+// Per-env clocks (aoenv_set_wind_env): the same launch also ADVANCES the clock of (env, layer) -- every env has its own wind, so
+// which envs cross a pixel this step is decided here, on the device, with the host clock's arithmetic (clock_subpixel, common.hpp).
+// Both workgroups of an env read clk_in and come to the same verdict; blockIdx.x == 0 writes the advanced clock to clk_out (the host
+// swaps the two) and this step's taps; an env that crosses gathers its Z through its OLD origin and draws its innovations in place.
+template <typename T>
+__global__ void __launch_bounds__(256) k_ring_prepare_env(const T* __restrict__ map, T* __restrict__ zx,
+                                                          const int* __restrict__ inner_idx, uint32_t* mt_state, int* mt_pos,
+                                                          const EnvClock* __restrict__ clk_in, EnvClock* __restrict__ clk_out,
+                                                          LayerTaps* __restrict__ taps, double weight, int S, int n_inner,
+                                                          int n_outer, int K) {
+    const int e = blockIdx.y;
+    EnvClock c = clk_in[e];
+    const int oy = c.org[0], ox = c.org[1];
+    int bx, by;
+    const bool cross = clock_subpixel(c.ratio, c.buff, &bx, &by);
+    if (blockIdx.x == 0) {
+        if (cross) gather_ring<T>(map, zx, inner_idx, S, n_inner, K, bx, by, oy, ox, e, threadIdx.x, 256);
+        if (threadIdx.x == 0) {
+            c.org[0] = ((oy - by) % S + S) % S;
+            c.org[1] = ((ox - bx) % S + S) % S;
+            clk_out[e] = c;
+            LayerTaps t;
+            t.oy = c.org[0];
+            t.ox = c.org[1];
+            taps_from_buff(c.buff, t);
+            t.weight = weight;
+            t.ring = cross ? 1 : 0;
+            t.pad_ = 0;
+            taps[e] = t;
+        }
+    } else if (cross) {
+        mt_normal_body<T>(mt_state, mt_pos, mt_state, mt_pos, zx, K, n_inner, n_outer, e);
+    }
+}
+
+template <typename T>
+int launch_ring_prepare_env(const T* map, T* zx, const int* inner_idx, uint32_t* mt_state, int* mt_pos, const EnvClock* clk_in,
+                            EnvClock* clk_out, LayerTaps* taps, double weight, int n_env, int S, int n_inner, int n_outer, int K,
+                            hipStream_t st) {
+    if (n_outer % 2) return fail("mt_normal: n_outer=%d must be even", n_outer);
+    hipLaunchKernelGGL(k_ring_prepare_env<T>, dim3(2, n_env), dim3(256), 0, st, map, zx, inner_idx, mt_state, mt_pos, clk_in, clk_out,
+                       taps, weight, S, n_inner, n_outer, K);
+    AO_HIP(hipGetLastError());
+    return 0;
+}
+
 template <typename T>
 int launch_mt_normal(uint32_t* mt_state, int* mt_pos, T* zx, int n_env, int K, int n_inner, int n_outer,
                      hipStream_t st) {
@@ -241,8 +287,13 @@ template <typename T>
 __global__ void __launch_bounds__(1024) k_scatter_minmax(T* __restrict__ new_map, const T* __restrict__ X,
                                                          const int* __restrict__ outer_idx, T* __restrict__ minmax,
                                                          int S, int n_outer, int splits, size_t slab, int oy, int ox,
-                                                         int with_minmax) {
+                                                         int with_minmax, const LayerTaps* __restrict__ env_taps) {
     const int e = blockIdx.x;
+    if (env_taps) {                                                // per-env clocks: only the envs that crossed, through their origin
+        if (!env_taps[e].ring) return;
+        oy = env_taps[e].oy;
+        ox = env_taps[e].ox;
+    }
     T* map = new_map + (size_t)e * S * S;
     const T* x = X + (size_t)e * n_outer;
     for (int k = threadIdx.x; k < n_outer; k += blockDim.x) {
@@ -258,9 +309,9 @@ __global__ void __launch_bounds__(1024) k_scatter_minmax(T* __restrict__ new_map
 
 template <typename T>
 int launch_scatter_minmax(T* new_map, const T* X, const int* outer_idx, T* minmax, int n_env, int S, int n_outer,
-                          int splits, int oy, int ox, int with_minmax, hipStream_t st) {
+                          int splits, int oy, int ox, int with_minmax, hipStream_t st, const LayerTaps* env_taps) {
     hipLaunchKernelGGL(k_scatter_minmax<T>, dim3(n_env), dim3(with_minmax ? 1024 : 512), 0, st, new_map, X, outer_idx, minmax, S,
-                       n_outer, splits, (size_t)n_env * n_outer, oy, ox, with_minmax);
+                       n_outer, splits, (size_t)n_env * n_outer, oy, ox, with_minmax, env_taps);
     AO_HIP(hipGetLastError());
     return 0;
 }
@@ -283,7 +334,9 @@ int launch_minmax(const T* maps, T* minmax, int n_env, int S, hipStream_t st) {
                                         int, int, int, int, int, int, hipStream_t);                                \
     template int launch_mt_normal<T>(uint32_t*, int*, T*, int, int, int, int, hipStream_t);                        \
     template int launch_scatter_minmax<T>(T*, const T*, const int*, T*, int, int, int, int, int, int, int,         \
-                                          hipStream_t);                                                            \
+                                          hipStream_t, const LayerTaps*);                                          \
+    template int launch_ring_prepare_env<T>(const T*, T*, const int*, uint32_t*, int*, const EnvClock*, EnvClock*, LayerTaps*, \
+                                            double, int, int, int, int, int, hipStream_t);                                                          \
     template int launch_minmax<T>(const T*, T*, int, int, hipStream_t);
 INST(float)
 INST(double)

@@ -42,7 +42,52 @@ struct LayerTaps {
     int dy, dx;            // floor(-buff_y), floor(-buff_x)  in {-1, 0}
     double wy[4], wx[4];   // Catmull-Rom weights of the taps at floor-1 .. floor+2
     double weight;         // sqrt(fractionalR0)
+    int ring;              // per-env clocks only: 1 = this env's layer crossed a pixel this step (its ring is to be scattered)
+    int pad_;
 };
+
+// ---- the atmosphere clock of one (env, layer): OOPAO/Atmosphere.py:350-407 ------------------------------------------------
+// Shared by the host (one clock per layer for the whole shard, aoenv_set_wind) and the device (one clock per env and layer,
+// aoenv_set_wind_env: k_ring_prepare_env): the same source, compiled without floating-point contraction, so that an env
+// stepped by its own clock is bit-identical to a shard stepped by the host clock with that wind.
+struct EnvClock {
+    double ratio[2];       // pixels per frame (x, y), |ratio| < 1 for per-env clocks          Atmosphere.py:362-363
+    double buff[2];        // sub-pixel accumulator                                             Atmosphere.py:392-404
+    int org[2];            // torus origin (oy, ox)
+    int pad_[2];
+};
+
+__host__ __device__ inline double clock_sgn(double v) { return (double)((v > 0) - (v < 0)); }
+
+__host__ __device__ inline void catmull_rom(double x, double w[4]) {
+#pragma clang fp contract(off)
+    w[0] = 0.5 * (-x * x * x + 2 * x * x - x);
+    w[1] = 0.5 * (3 * x * x * x - 5 * x * x + 2);
+    w[2] = 0.5 * (-3 * x * x * x + 4 * x * x + x);
+    w[3] = 0.5 * (x * x * x - x * x);
+}
+
+// the sub-pixel part of updateLayer: buff += frac(|ratio|) sign(ratio); a pixel is crossed where |buff| >= 1: *bx, *by in
+// {-1, 0, 1} (the caller extrudes the ring and moves the origin); buff keeps its fractional part.
+__host__ __device__ inline bool clock_subpixel(const double ratio[2], double buff[2], int* bx, int* by) {
+#pragma clang fp contract(off)
+    for (int d = 0; d < 2; ++d) buff[d] += fmod(fabs(ratio[d]), 1.0) * clock_sgn(ratio[d]);
+    *bx = fabs(buff[0]) < 1 ? 0 : (int)clock_sgn(buff[0]);
+    *by = fabs(buff[1]) < 1 ? 0 : (int)clock_sgn(buff[1]);
+    for (int d = 0; d < 2; ++d) buff[d] = fmod(fabs(buff[d]), 1.0) * clock_sgn(buff[d]);
+    return *bx != 0 || *by != 0;
+}
+
+// tap offsets and weights of the sub-pixel warp for the accumulator `buff` (OOPAO/Atmosphere.py:406-407)
+__host__ __device__ inline void taps_from_buff(const double buff[2], LayerTaps& t) {
+#pragma clang fp contract(off)
+    const double fy = -buff[1], fx = -buff[0];
+    const double ky = floor(fy), kx = floor(fx);
+    t.dy = (int)ky;
+    t.dx = (int)kx;
+    catmull_rom(fy - ky, t.wy);
+    catmull_rom(fx - kx, t.wx);
+}
 
 struct PhaseArgs {
     const void* screen[kMaxLayer];   // current mapShift of each layer, [n_env][(N+2)^2]
@@ -55,7 +100,14 @@ struct PhaseArgs {
     int store_atm;                   // 1: also write atm.OPD_no_pupil to the opd_atm buffer (state inspection)
     int store_phase;                 // 0: leave the residual phase, the telemetry sums and wfs_max untouched
     int minmax_dirty[kMaxLayer];     // fused step kernel: 1 = recompute the layer's min / max from the map and store it
+    const LayerTaps* env_taps;       // per-env clocks (aoenv_set_wind_env): [n_layer][n_env] taps of THIS step, else null
+    int n_env;                       // row length of env_taps
 };
+
+// the taps of (layer l, env e): the env's own when the shard runs per-env clocks, else the layer's
+__device__ inline const LayerTaps& layer_taps(const PhaseArgs& pa, int l, int e) {
+    return pa.env_taps ? pa.env_taps[(size_t)l * pa.n_env + e] : pa.taps[l];
+}
 
 }  // namespace ao
 
@@ -73,7 +125,11 @@ int launch_mt_normal(uint32_t* mt_state, int* mt_pos, T* zx, int n_env, int K, i
                      hipStream_t st);
 template <typename T>
 int launch_scatter_minmax(T* new_map, const T* X, const int* outer_idx, T* minmax, int n_env, int S, int n_outer,
-                          int splits, int oy, int ox, int with_minmax, hipStream_t st);
+                          int splits, int oy, int ox, int with_minmax, hipStream_t st, const LayerTaps* env_taps = nullptr);
+template <typename T>
+int launch_ring_prepare_env(const T* map, T* zx, const int* inner_idx, uint32_t* mt_state, int* mt_pos, const EnvClock* clk_in,
+                            EnvClock* clk_out, LayerTaps* taps, double weight, int n_env, int S, int n_inner, int n_outer, int K,
+                            hipStream_t st);
 template <typename T>
 int launch_minmax(const T* maps, T* minmax, int n_env, int S, hipStream_t st);
 int gemm_splits(int M, int N, int K);

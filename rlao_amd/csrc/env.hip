@@ -41,6 +41,11 @@ struct AoEnv {
     LayerClock clk[kMaxLayer];
     int org[kMaxLayer][2] = {{0, 0}};        // torus origin (oy, ox) of every layer: logical (r, c) at ((r + oy) % S, (c + ox) % S)
     int ring_pending[kMaxLayer] = {0};       // > 0: split count of a ring extrusion whose scatter the next fused step kernel will do
+    // per-env clocks (aoenv_set_wind_env): every env its own wind vector per layer; clocks, origins and taps live on the device
+    bool per_env_wind = false;
+    EnvClock* env_clk[2] = {nullptr, nullptr};   // [L][E] each: current / next (k_ring_prepare_env reads one, writes the other)
+    int clk_cur = 0;
+    LayerTaps* env_taps = nullptr;           // [L][E] taps of the current step
     bool use_coefs_img = false;              // aoenv_set_option(AOENV_OPT_COEFS_IMAGE); always on above 1024 actuators
     bool defer_ring = true;                  // aoenv_set_option(AOENV_OPT_DEFER_RING)
     bool minmax_dirty[kMaxLayer] = {false};  // the layer's min / max table is stale (ring extruded without the min / max pass)
@@ -206,13 +211,6 @@ int upload_real(AoEnv* env, void* dst, const double* src, size_t n) {
 double sgn(double v) { return (v > 0) - (v < 0); }
 
 // Catmull-Rom tap weights of skimage's cubic_interpolation() for fractional offset x in [0, 1)
-void catmull_rom(double x, double w[4]) {
-    w[0] = 0.5 * (-x * x * x + 2 * x * x - x);
-    w[1] = 0.5 * (3 * x * x * x - 5 * x * x + 2);
-    w[2] = 0.5 * (-3 * x * x * x + 4 * x * x + x);
-    w[3] = 0.5 * (x * x * x - x * x);
-}
-
 void mt_seed(uint32_t seed, uint32_t* key) {          // numpy legacy mt19937_seed / init_genrand
     for (int pos = 0; pos < kMtN; ++pos) {
         key[pos] = seed;
@@ -258,9 +256,12 @@ template <typename T>
 int flush_ring(AoEnv* env, int l, hipStream_t st) {
     if (!env->ring_pending[l]) return 0;
     AO_PROF(env, SCATTER, st);
+    // (per-env clocks: only the envs that crossed, each through its own origin, and their range right away -- there is no
+    //  per-env "dirty" flag on the host)
+    const LayerTaps* et = env->per_env_wind ? env->env_taps + (size_t)l * env->E : nullptr;
     AO_TRY(launch_scatter_minmax<T>(env->as<T>(env->screen_ptr(0, l)), static_cast<const T*>(env->ring_src[l]), env->outer_idx,
                                     env->as<T>(env->minmax_ptr(l)), env->E, env->S, env->nout, env->ring_pending[l],
-                                    env->org[l][0], env->org[l][1], 0, st));
+                                    env->org[l][0], env->org[l][1], et ? 1 : 0, st, et));
     env->ring_pending[l] = 0;
     return 0;
 }
@@ -340,8 +341,38 @@ int refresh_minmax(AoEnv* env, hipStream_t st) {
 }
 
 // ---- atm.update(): host clock of updateLayer (OOPAO/Atmosphere.py:350-407) -----------------------
+// Per-env clocks: one launch per layer advances every env's clock on the device and prepares [Z | xi] of the envs that cross a
+// pixel; the ring GEMM runs over the whole shard (rows of the other envs are computed and never used: which envs cross is
+// not known on the host, and with independent winds some env crosses on nearly every step anyway).
+template <typename T>
+int advance_atmosphere_env(AoEnv* env, bool lean, hipStream_t st) {
+    for (int l = 0; l < env->L; ++l) {
+        AO_TRY(flush_ring<T>(env, l, st));
+        T* map = env->as<T>(env->screen_ptr(0, l));
+        T* zx = env->as<T>(env->zx);
+        const size_t row = (size_t)l * env->E;
+        {
+            AO_PROF(env, SHIFT_GATHER, st);
+            AO_TRY(launch_ring_prepare_env<T>(map, zx, env->inner_idx, env->mt_cur[l], env->pos_cur[l], env->env_clk[env->clk_cur] + row,
+                                              env->env_clk[1 - env->clk_cur] + row, env->env_taps + row, env->layer_weight[l], env->E,
+                                              env->S, env->nin, env->nout, env->K, st));
+        }
+        int splits = 1;
+        {
+            AO_PROF(env, GEMM_RING, st);
+            AO_TRY(gemm_dispatch<T>(env, zx, env->as<T>(env->ab), env->as<T>(env->xbuf_ptr(l)), env->E, env->nout, env->K, &splits, st));
+        }
+        env->ring_pending[l] = splits;
+        env->ring_src[l] = env->xbuf_ptr(l);
+        if (!(lean && env->defer_ring)) AO_TRY(flush_ring<T>(env, l, st));
+    }
+    env->clk_cur = 1 - env->clk_cur;
+    return 0;
+}
+
 template <typename T>
 int advance_atmosphere(AoEnv* env, bool lean, hipStream_t st) {
+    if (env->per_env_wind) return advance_atmosphere_env<T>(env, lean, st);
     for (int l = 0; l < env->L; ++l) {
         LayerClock& k = env->clk[l];
         if (k.ratio[0] == 0 && k.ratio[1] == 0) continue;
@@ -351,10 +382,8 @@ int advance_atmosphere(AoEnv* env, bool lean, hipStream_t st) {
         for (int i = 0; i < mn; ++i) AO_TRY(extrude<T>(env, l, s0, s1, lean, st));
         for (int j = 0; j < mx - mn; ++j)
             AO_TRY(extrude<T>(env, l, ns[0] == mn ? 0 : s0, ns[1] == mn ? 0 : s1, lean, st));
-        for (int d = 0; d < 2; ++d) k.buff[d] += std::fmod(std::fabs(k.ratio[d]), 1.0) * sgn(k.ratio[d]);
-        if (std::fabs(k.buff[0]) >= 1 || std::fabs(k.buff[1]) >= 1) {
-            const int b0 = std::fabs(k.buff[0]) < 1 ? 0 : (int)sgn(k.buff[0]);
-            const int b1 = std::fabs(k.buff[1]) < 1 ? 0 : (int)sgn(k.buff[1]);
+        int b0, b1;
+        if (clock_subpixel(k.ratio, k.buff, &b0, &b1)) {          // (the arithmetic the per-env device clocks share, common.hpp)
             AoEnv::RingAhead& ah = env->ahead[l];
             if (lean && env->defer_ring && ah.valid && ah.sx == b0 && ah.sy == b1 && !env->ring_pending[l]) {
                 // the extrusion of this crossing was computed ahead: wait for it, commit its stream copy, move the torus origin
@@ -372,7 +401,6 @@ int advance_atmosphere(AoEnv* env, bool lean, hipStream_t st) {
                 AO_TRY(extrude<T>(env, l, b0, b1, lean, st, lean && env->defer_ring));
             }
         }
-        for (int d = 0; d < 2; ++d) k.buff[d] = std::fmod(std::fabs(k.buff[d]), 1.0) * sgn(k.buff[d]);
     }
     return 0;
 }
@@ -575,14 +603,11 @@ void fill_phase_args(AoEnv* env, PhaseArgs& pa, PhaseBuffers<T>& pb, int update_
         LayerTaps& t = pa.taps[l];
         t.oy = env->org[l][0];
         t.ox = env->org[l][1];
-        const double fy = -env->clk[l].buff[1], fx = -env->clk[l].buff[0];
-        const double ky = std::floor(fy), kx = std::floor(fx);
-        t.dy = (int)ky;
-        t.dx = (int)kx;
-        catmull_rom(fy - ky, t.wy);
-        catmull_rom(fx - kx, t.wx);
+        taps_from_buff(env->clk[l].buff, t);
         t.weight = env->layer_weight[l];
     }
+    pa.env_taps = env->per_env_wind ? env->env_taps : nullptr;
+    pa.n_env = env->E;
     pb = PhaseBuffers<T>{};
     pb.opd_atm = env->as<T>(env->opd_atm);
     pb.coefs = env->as<T>(env->coefs);
@@ -1131,9 +1156,142 @@ int aoenv_upload(AoEnv* env, int kind, const void* h, size_t bytes) {
     return 0;
 }
 
+// ---- per-env clocks -----------------------------------------------------------------------------------------------------
+static int alloc_env_clocks(AoEnv* env) {
+    if (env->env_taps) return 0;
+    const size_t n = (size_t)env->L * env->E;
+    for (int b = 0; b < 2; ++b) {
+        void* p_ = nullptr;
+        AO_HIP(hipMalloc(&p_, n * sizeof(EnvClock)));
+        env->allocs.push_back(p_);
+        env->env_clk[b] = static_cast<EnvClock*>(p_);
+    }
+    void* t = nullptr;
+    AO_HIP(hipMalloc(&t, n * sizeof(LayerTaps)));
+    env->allocs.push_back(t);
+    env->env_taps = static_cast<LayerTaps*>(t);
+    return 0;
+}
+
+// host copy of the clocks -> device (current buffer) + the taps they imply (no ring pending)
+static int push_env_clocks(AoEnv* env, const std::vector<EnvClock>& clk) {
+    const size_t n = (size_t)env->L * env->E;
+    std::vector<LayerTaps> taps(n);
+    for (int l = 0; l < env->L; ++l)
+        for (int e = 0; e < env->E; ++e) {
+            const EnvClock& c = clk[(size_t)l * env->E + e];
+            LayerTaps& t = taps[(size_t)l * env->E + e];
+            t = LayerTaps{};
+            t.oy = c.org[0];
+            t.ox = c.org[1];
+            taps_from_buff(c.buff, t);
+            t.weight = env->layer_weight[l];
+        }
+    AO_HIP(hipMemcpy(env->env_clk[env->clk_cur], clk.data(), n * sizeof(EnvClock), hipMemcpyHostToDevice));
+    AO_HIP(hipMemcpy(env->env_taps, taps.data(), n * sizeof(LayerTaps), hipMemcpyHostToDevice));
+    return 0;
+}
+
+static int pull_env_clocks(AoEnv* env, std::vector<EnvClock>& clk) {
+    clk.resize((size_t)env->L * env->E);
+    AO_HIP(hipMemcpy(clk.data(), env->env_clk[env->clk_cur], clk.size() * sizeof(EnvClock), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int aoenv_set_wind_env(AoEnv* env, const double* h_ratio, int reset_buff, void* stream) {
+    AO_CHECK_ENV(env);
+    if (!h_ratio) return fail("null ratio");
+    const size_t n = (size_t)env->L * env->E;
+    for (size_t i = 0; i < 2 * n; ++i)
+        if (!(std::fabs(h_ratio[i]) < 1.0)) return fail("per-env wind: |ratio| = %g px/frame, must be < 1 (an env extrudes at most one ring per step)", std::fabs(h_ratio[i]));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    AO_TRY(drop_lookaheads(env, st));
+    AO_TRY(AO_DISPATCH(env, flush_rings, env, st));                // a deferred ring of the clocks as they were
+    AO_HIP(hipStreamSynchronize(st));
+    AO_TRY(alloc_env_clocks(env));
+    std::vector<EnvClock> clk;
+    if (env->per_env_wind) {
+        AO_TRY(pull_env_clocks(env, clk));
+    } else {                                                       // from the shared clock: every env starts where the shard is
+        clk.assign(n, EnvClock{});
+        for (int l = 0; l < env->L; ++l)
+            for (int e = 0; e < env->E; ++e) {
+                EnvClock& c = clk[(size_t)l * env->E + e];
+                c.buff[0] = env->clk[l].buff[0];
+                c.buff[1] = env->clk[l].buff[1];
+                c.org[0] = env->org[l][0];
+                c.org[1] = env->org[l][1];
+            }
+    }
+    for (size_t i = 0; i < n; ++i) {
+        clk[i].ratio[0] = h_ratio[2 * i];
+        clk[i].ratio[1] = h_ratio[2 * i + 1];
+        if (reset_buff) clk[i].buff[0] = clk[i].buff[1] = 0;
+    }
+    env->per_env_wind = true;
+    env->use_lookahead = false;
+    return push_env_clocks(env, clk);
+}
+
+int aoenv_get_clock_env(AoEnv* env, double* h_clock) {
+    AO_CHECK_ENV(env);
+    if (!h_clock) return fail("null argument");
+    if (!env->per_env_wind) return fail("the shard runs the shared clock (aoenv_set_wind): use aoenv_get_buff");
+    AO_HIP(hipDeviceSynchronize());
+    std::vector<EnvClock> clk;
+    AO_TRY(pull_env_clocks(env, clk));
+    for (size_t i = 0; i < clk.size(); ++i) {
+        h_clock[4 * i] = clk[i].ratio[0];
+        h_clock[4 * i + 1] = clk[i].ratio[1];
+        h_clock[4 * i + 2] = clk[i].buff[0];
+        h_clock[4 * i + 3] = clk[i].buff[1];
+    }
+    return 0;
+}
+
+int aoenv_set_clock_env(AoEnv* env, const double* h_clock) {
+    AO_CHECK_ENV(env);
+    if (!h_clock) return fail("null argument");
+    if (!env->per_env_wind) return fail("the shard runs the shared clock (aoenv_set_wind): use aoenv_set_buff");
+    AO_HIP(hipDeviceSynchronize());
+    std::vector<EnvClock> clk;
+    AO_TRY(pull_env_clocks(env, clk));                             // (keeps the origins)
+    for (size_t i = 0; i < clk.size(); ++i) {
+        for (int d = 0; d < 2; ++d) {
+            if (!(std::fabs(h_clock[4 * i + d]) < 1.0)) return fail("per-env wind: |ratio| must be < 1 px/frame");
+            if (!(std::fabs(h_clock[4 * i + 2 + d]) < 1.0)) return fail("|buff| must be < 1");
+            clk[i].ratio[d] = h_clock[4 * i + d];
+            clk[i].buff[d] = h_clock[4 * i + 2 + d];
+        }
+    }
+    for (int l = 0; l < env->L; ++l) env->ring_pending[l] = 0;
+    return push_env_clocks(env, clk);
+}
+
+// every env's clock back to the start of an episode: accumulators and origins zero (new screens / uploaded screens)
+static int reset_env_clocks(AoEnv* env, bool reset_buff) {
+    if (!env->per_env_wind) return 0;
+    std::vector<EnvClock> clk;
+    AO_TRY(pull_env_clocks(env, clk));
+    for (auto& c : clk) {
+        c.org[0] = c.org[1] = 0;
+        if (reset_buff) c.buff[0] = c.buff[1] = 0;
+    }
+    return push_env_clocks(env, clk);
+}
+
 int aoenv_set_wind(AoEnv* env, const double* h_ratio, int reset_buff) {
     AO_CHECK_ENV(env);
     if (!h_ratio) return fail("null ratio");
+    if (env->per_env_wind) {                                       // the shard keeps its per-env clocks: the same wind for every env
+        std::vector<double> r((size_t)env->L * env->E * 2);
+        for (int l = 0; l < env->L; ++l)
+            for (int e = 0; e < env->E; ++e) {
+                r[2 * ((size_t)l * env->E + e)] = h_ratio[2 * l];
+                r[2 * ((size_t)l * env->E + e) + 1] = h_ratio[2 * l + 1];
+            }
+        return aoenv_set_wind_env(env, r.data(), reset_buff, nullptr);
+    }
     for (int l = 0; l < env->L; ++l) {
         env->clk[l].ratio[0] = h_ratio[2 * l];
         env->clk[l].ratio[1] = h_ratio[2 * l + 1];
@@ -1167,10 +1325,16 @@ static int finish_new_screens(AoEnv* env, const uint32_t* h_ring_seeds, hipStrea
         AO_HIP(hipMemcpy(env->mt_cur[l], keys.data(), keys.size() * 4, hipMemcpyHostToDevice));
         AO_HIP(hipMemcpy(env->pos_cur[l], pos.data(), pos.size() * 4, hipMemcpyHostToDevice));
     }
+    AO_HIP(hipStreamSynchronize(st));
+    AO_TRY(reset_env_clocks(env, true));                           // per-env clocks: accumulators and origins of every env to zero
+    const bool pe = env->per_env_wind;
+    env->per_env_wind = false;                                     // the first ring is one extrusion of the whole shard, origin 0
     for (int l = 0; l < L; ++l) {
         env->clk[l].buff[0] = env->clk[l].buff[1] = 0;            // notDoneOnce (OOPAO/Atmosphere.py:586, 359-364)
-        AO_TRY(AO_DISPATCH(env, extrude, env, l, 0, 0, false, st));   // (the callers reset the torus origin with the new interior)
+        const int rc = AO_DISPATCH(env, extrude, env, l, 0, 0, false, st);   // (the callers reset the torus origin with the new interior)
+        if (rc) { env->per_env_wind = pe; return rc; }
     }
+    env->per_env_wind = pe;
     env->atm_user_defined = false;
     AO_TRY(AO_DISPATCH(env, run_phase, env, 1, 1, st));            // fill_phase_support + set_OPD + atm*tel
     return 0;
@@ -1492,17 +1656,21 @@ int aoenv_download(AoEnv* env, int which, void* h_dst, size_t bytes, void* strea
         const int S = env->S;
         const size_t per = (size_t)env->E * S * S * env->esz, z = env->esz;
         std::vector<char> tmp(per);
+        std::vector<EnvClock> clk_h;
+        if (env->per_env_wind) AO_TRY(pull_env_clocks(env, clk_h));
         for (int l = 0; l < env->L; ++l) {
             AO_HIP(hipMemcpy(tmp.data(), env->screen_ptr(0, l), per, hipMemcpyDeviceToHost));
             char* dst = static_cast<char*>(h_dst) + l * per;
-            const int oy = env->org[l][0], ox = env->org[l][1];
-            for (int e = 0; e < env->E; ++e)
+            for (int e = 0; e < env->E; ++e) {
+                const int oy = env->per_env_wind ? clk_h[(size_t)l * env->E + e].org[0] : env->org[l][0];
+                const int ox = env->per_env_wind ? clk_h[(size_t)l * env->E + e].org[1] : env->org[l][1];
                 for (int r = 0; r < S; ++r) {
                     const char* srow = tmp.data() + ((size_t)e * S * S + (size_t)((r + oy) % S) * S) * z;
                     char* drow = dst + ((size_t)e * S * S + (size_t)r * S) * z;
                     std::memcpy(drow, srow + (size_t)ox * z, (size_t)(S - ox) * z);
                     std::memcpy(drow + (size_t)(S - ox) * z, srow, (size_t)ox * z);
                 }
+            }
         }
         return 0;
     }
@@ -1554,7 +1722,7 @@ int aoenv_upload_state(AoEnv* env, int which, const void* h_src, size_t bytes, v
             env->minmax_dirty[l] = true;
         }
         env->atm_user_defined = false;
-        return 0;
+        return reset_env_clocks(env, false);                       // per-env clocks: origins to zero, accumulators kept
     }
     if (which == AOENV_B_MT_STATE) {
         const size_t n = (size_t)env->L * env->E;
@@ -1584,12 +1752,14 @@ int aoenv_upload_state(AoEnv* env, int which, const void* h_src, size_t bytes, v
 
 int aoenv_get_buff(AoEnv* env, double* h_buff) {
     if (!env || !h_buff) return fail("null argument");
+    if (env->per_env_wind) return fail("the shard runs per-env clocks (aoenv_set_wind_env): use aoenv_get_clock_env");
     for (int l = 0; l < env->L; ++l) { h_buff[2 * l] = env->clk[l].buff[0]; h_buff[2 * l + 1] = env->clk[l].buff[1]; }
     return 0;
 }
 
 int aoenv_set_buff(AoEnv* env, const double* h_buff) {
     if (!env || !h_buff) return fail("null argument");
+    if (env->per_env_wind) return fail("the shard runs per-env clocks (aoenv_set_wind_env): use aoenv_set_clock_env");
     for (int l = 0; l < env->L; ++l) {
         if (std::fabs(h_buff[2 * l]) >= 1 || std::fabs(h_buff[2 * l + 1]) >= 1) return fail("|buff| must be < 1");
         env->clk[l].buff[0] = h_buff[2 * l]; env->clk[l].buff[1] = h_buff[2 * l + 1];

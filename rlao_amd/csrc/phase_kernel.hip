@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(256) k_phase(const KArgs<T> a) {
 
     if (a.pa.update_atm) {
         for (int l = 0; l < a.pa.n_layer; ++l) {
-            const LayerTaps& tp = a.pa.taps[l];
+            const LayerTaps& tp = layer_taps(a.pa, l, e);
             const T* map = static_cast<const T*>(a.pa.screen[l]) + (size_t)e * S * S;
             const int r0 = y0 + a.pa.foot + tp.dy - 1, c0 = x0 + a.pa.foot + tp.dx - 1;
             __syncthreads();                                  // previous layer's tiles are no longer read
@@ -291,7 +291,7 @@ __global__ void __launch_bounds__(256) k_phase_mfma(const KArgs<float> a) {
 
     if (a.pa.update_atm && !(a.ablate & 2)) {
         for (int l = 0; l < a.pa.n_layer; ++l) {
-            const LayerTaps& tp = a.pa.taps[l];
+            const LayerTaps& tp = layer_taps(a.pa, l, e);
             const float* map = static_cast<const float*>(a.pa.screen[l]) + (size_t)e * S * S;
             const int r0 = y0 + a.pa.foot + tp.dy - 1, c0 = x0 + a.pa.foot + tp.dx - 1;
             __syncthreads();                                  // the previous layer's tile is no longer read

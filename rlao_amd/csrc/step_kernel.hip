@@ -85,8 +85,16 @@ static StepLds step_lds_layout(int n_act, int n_subap, int n_valid, int n_modes)
     return L;
 }
 
+template <bool PE>
+__device__ inline const LayerTaps& step_taps(const PhaseArgs& pa, int l, int e) {
+    if constexpr (PE) return pa.env_taps[(size_t)l * pa.n_env + e];
+    else return pa.taps[l];
+}
+
 // KS: k steps (of 4) of the DM product whose B operands are held in registers, n_act <= 4 KS
-template <int KS>
+// PE: per-env clocks (aoenv_set_wind_env): the layer taps come from the env's own record in global memory instead of the kernel
+// arguments (a variant of its own: read through a pointer chosen at run time, the shared-clock path lost 3 %)
+template <int KS, bool PE>
 __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const StepLds L) {
     using namespace fstep;
     using fast6::EST;
@@ -195,10 +203,12 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
         for (int l = 0; l < k.pa.n_layer; ++l) {
             const float* x = a.ring_x[l];
             if (x == nullptr) continue;
-            any = true;
+            any = true;                                           // (uniform over the workgroup: the barrier below)
+            const LayerTaps& tl = step_taps<PE>(k.pa, l, e);
+            if (PE && !tl.ring) continue;              // per-env clocks: this env's layer did not cross a pixel
             float* map = const_cast<float*>(static_cast<const float*>(k.pa.screen[l])) + (size_t)e * S * S;
             const size_t slab = (size_t)a.n_env * a.n_outer;
-            const int oy = k.pa.taps[l].oy, ox = k.pa.taps[l].ox;
+            const int oy = tl.oy, ox = tl.ox;
             for (int q = tid; q < a.n_outer; q += 1024) {
                 float xv[kMaxSplits];                             // all slabs in flight at once, summed in slab order
 #pragma unroll
@@ -222,7 +232,8 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
     __shared__ float red_lo[16], red_hi[16];
     for (int l = 0; l < k.pa.n_layer; ++l) {
         float* mm = const_cast<float*>(static_cast<const float*>(k.pa.minmax[l])) + 2 * e;
-        if (!k.pa.minmax_dirty[l]) {
+        const bool dirty = k.pa.minmax_dirty[l] || (PE && a.ring_x[l] != nullptr && step_taps<PE>(k.pa, l, e).ring);
+        if (!dirty) {
             float pre = 0.f;
 #pragma unroll
             for (int q = 0; q < kMaxLayer; ++q) pre = q == l ? mm_pre[q] : pre;
@@ -289,7 +300,7 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) sup[tt] = f32x4s{0.f, 0.f, 0.f, 0.f};
         for (int l = 0; l < k.pa.n_layer; ++l) {
-            const LayerTaps& tp = k.pa.taps[l];
+            const LayerTaps& tp = step_taps<PE>(k.pa, l, e);
             const float* map = static_cast<const float*>(k.pa.screen[l]) + (size_t)e * S * S;
             const int r0 = y0 + k.pa.foot + tp.dy - 1, c0 = k.pa.foot + tp.dx - 1;
             // Every wave stages ITS tile (16 rows x 32 columns + the 4 x 4 stencil apron) in a private LDS slice: no
@@ -893,15 +904,20 @@ int step_fused_supported(int R, int n_subap, int n_valid, int n_act, int n_modes
 int launch_env_step(const StepArgs& a, hipStream_t st) {
     const StepLds L = step_lds_layout(a.k.n_act, a.n_subap, a.n_valid, a.n_modes);
     const size_t lds = (size_t)L.total * 4;
-    static size_t attr_set[2] = {0, 0};
     const int v = a.k.n_act <= 24 ? 0 : 1;
-    const void* fn = v == 0 ? reinterpret_cast<const void*>(k_env_step_sh6<6>) : reinterpret_cast<const void*>(k_env_step_sh6<8>);
-    if (lds > 64 * 1024 && lds > attr_set[v]) {
+    const bool pe = a.k.pa.env_taps != nullptr;
+    const void* fn = v == 0 ? (pe ? reinterpret_cast<const void*>(k_env_step_sh6<6, true>) : reinterpret_cast<const void*>(k_env_step_sh6<6, false>))
+                            : (pe ? reinterpret_cast<const void*>(k_env_step_sh6<8, true>) : reinterpret_cast<const void*>(k_env_step_sh6<8, false>));
+    static size_t attr_set[4] = {0, 0, 0, 0};
+    const int vi = 2 * v + (pe ? 1 : 0);
+    if (lds > 64 * 1024 && lds > attr_set[vi]) {
         AO_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set[v] = lds;
+        attr_set[vi] = lds;
     }
-    if (v == 0) hipLaunchKernelGGL(k_env_step_sh6<6>, dim3(a.n_env), dim3(1024), lds, st, a, L);
-    else hipLaunchKernelGGL(k_env_step_sh6<8>, dim3(a.n_env), dim3(1024), lds, st, a, L);
+    if (v == 0 && !pe) hipLaunchKernelGGL((k_env_step_sh6<6, false>), dim3(a.n_env), dim3(1024), lds, st, a, L);
+    else if (v == 0) hipLaunchKernelGGL((k_env_step_sh6<6, true>), dim3(a.n_env), dim3(1024), lds, st, a, L);
+    else if (!pe) hipLaunchKernelGGL((k_env_step_sh6<8, false>), dim3(a.n_env), dim3(1024), lds, st, a, L);
+    else hipLaunchKernelGGL((k_env_step_sh6<8, true>), dim3(a.n_env), dim3(1024), lds, st, a, L);
     AO_HIP(hipGetLastError());
     return 0;
 }

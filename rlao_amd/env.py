@@ -119,6 +119,20 @@ class Shard:
         b = np.ascontiguousarray(buff, dtype=np.float64)
         L.check(self.lib.aoenv_set_buff(self.h, b.ctypes.data_as(C.c_void_p)))
 
+    # per-env clocks: ratio [n_layer][n_env][2] pixels per frame; clock [n_layer][n_env][4] = (ratio x, y, buff x, y)
+    def set_wind_env(self, ratio: np.ndarray, reset_buff: bool, stream=0):
+        r = np.ascontiguousarray(ratio, dtype=np.float64)
+        L.check(self.lib.aoenv_set_wind_env(self.h, r.ctypes.data_as(C.c_void_p), int(reset_buff), C.c_void_p(stream)))
+
+    def get_clock_env(self, n_layer: int, n_env: int) -> np.ndarray:
+        out = np.zeros((n_layer, n_env, 4))
+        L.check(self.lib.aoenv_get_clock_env(self.h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def set_clock_env(self, clock):
+        c = np.ascontiguousarray(clock, dtype=np.float64)
+        L.check(self.lib.aoenv_set_clock_env(self.h, c.ctypes.data_as(C.c_void_p)))
+
 
 # ----------------------------------------------------------------------------------------------------
 # reach-through proxies (only the uses listed in SURVEY.md 8b)
@@ -135,8 +149,12 @@ class _AtmProxy:
 
     @windSpeed.setter
     def windSpeed(self, val):
-        """OOPAO/Atmosphere.py:829-847: new ratio, the sub-pixel accumulator is kept."""
+        """OOPAO/Atmosphere.py:829-847: new ratio, the sub-pixel accumulator is kept.  A 2-D value [n_envs, nLayer] gives every
+        env its own wind speed (the shard switches to per-env clocks, see set_wind_per_env)."""
         e = self._e
+        if np.ndim(val) == 2:
+            e.set_wind_per_env(speed=val)
+            return
         if len(val) != e.param.nLayer:
             print("Error! Wrong value for the wind-speed! Make sure that you inpute a wind-speed for each layer")
             return
@@ -150,6 +168,9 @@ class _AtmProxy:
     @windDirection.setter
     def windDirection(self, val):
         e = self._e
+        if np.ndim(val) == 2:
+            e.set_wind_per_env(direction=val)
+            return
         if len(val) != e.param.nLayer:
             print("Error! Wrong value for the wind-speed! Make sure that you inpute a wind-speed for each layer")
             return
@@ -392,6 +413,8 @@ class BatchedAOEnv:
         self.atm = self.dm = self.tel = self.wfs = None
         self._shard = None
         self._done = None
+        self._wind_env = None                                      # (speed, direction) [n_envs, nLayer] once per-env winds are set
+        self._per_env_clock = False
 
     # -- construction --------------------------------------------------------------------------------
     def set_params_file(self, param_file, oopao_path):
@@ -645,7 +668,27 @@ class BatchedAOEnv:
 
     def _push_wind(self, reset: bool):
         p = self.param
+        self._wind_env = None                                      # one wind for the shard again (per-env clocks stay per-env)
         self._shard.set_wind(self._atm_tables.wind_ratio(p.windSpeed, p.windDirection, p.samplingTime), reset)
+
+    def set_wind_per_env(self, speed=None, direction=None, reset: bool = False):
+        """Every env its own wind: ``speed`` [m/s] and ``direction`` [deg] of shape [n_envs, nLayer] (one of them may be None:
+        the shard's current value).  What a trainer does that draws the wind per run (MAIN/integrator_oopao_razor.py:41-44,
+        OOPAO/Atmosphere.py:829-873), batched: env e then evolves exactly like a shard whose shared wind is (speed[e],
+        direction[e]).  At most one pixel per frame and axis.  ``atm.windSpeed = array2d`` / ``atm.windDirection = array2d`` call this."""
+        p = self.param
+        cur_s, cur_d = (self._wind_env if self._wind_env is not None else
+                        (np.tile(np.asarray(p.windSpeed, float), (self.n_envs, 1)), np.tile(np.asarray(p.windDirection, float), (self.n_envs, 1))))
+        s = cur_s if speed is None else np.asarray(speed, dtype=np.float64)
+        d = cur_d if direction is None else np.asarray(direction, dtype=np.float64)
+        if s.shape != (self.n_envs, p.nLayer) or d.shape != (self.n_envs, p.nLayer):
+            raise ValueError(f"per-env wind: speed / direction must be [n_envs={self.n_envs}, nLayer={p.nLayer}]")
+        ratio = np.zeros((p.nLayer, self.n_envs, 2))
+        for e in range(self.n_envs):
+            ratio[:, e] = self._atm_tables.wind_ratio(s[e], d[e], p.samplingTime)
+        self._shard.set_wind_env(ratio, reset, self._stream())
+        self._wind_env = (s.copy(), d.copy())
+        self._per_env_clock = True
 
     def env_seeds(self, seed: int) -> np.ndarray:
         idx = np.arange(self.n_envs, dtype=np.int64) + self.env_index_offset
@@ -673,7 +716,10 @@ class BatchedAOEnv:
             if screens.shape != (self.n_envs, p.nLayer, at.N, at.N):
                 raise ValueError(f"screens must have shape ({self.n_envs}, {p.nLayer}, {at.N}, {at.N})")
             self._shard.new_screens(screens.reshape(self.n_envs, p.nLayer, at.N * at.N), ring, self._stream())
-        self._push_wind(reset=True)
+        if self._wind_env is not None:
+            self.set_wind_per_env(reset=True)                       # every env keeps its own wind over the episodes
+        else:
+            self._push_wind(reset=True)
 
     def measure(self):
         """tel*dm*wfs: one WFS measurement of (atmosphere + DM), no turbulence update."""
@@ -746,7 +792,9 @@ class BatchedAOEnv:
         st = self._stream()
         return {
             "screen": sh.download(L.B_SCREEN, (p.nLayer, self.n_envs, at.S, at.S), st),
-            "buff": sh.get_buff(p.nLayer).copy(),
+            "buff": None if self._per_env_clock else sh.get_buff(p.nLayer).copy(),
+            "clock_env": sh.get_clock_env(p.nLayer, self.n_envs) if self._per_env_clock else None,
+            "wind_env": self._wind_env,
             "mt": sh.download(L.B_MT_STATE, (p.nLayer, self.n_envs, 625), st, dtype=np.uint32),
             "coefs": sh.download(L.B_COEFS, (self.n_envs, self.nValidAct), st),
             "dm_prev": sh.download(L.B_DM_PREV, (self.n_envs, self.nValidAct), st),
@@ -760,9 +808,19 @@ class BatchedAOEnv:
         sh, p = self._shard, self.param
         st = self._stream()
         p.windSpeed, p.windDirection = list(state["windSpeed"]), list(state["windDirection"])
-        self._push_wind(reset=False)
-        sh.upload_state(L.B_SCREEN, state["screen"], st)
-        sh.set_buff(state["buff"])
+        if state.get("clock_env") is not None:                       # per-env clocks: ratios and accumulators of every env
+            clk = np.asarray(state["clock_env"])
+            self._shard.set_wind_env(clk[..., :2], False, st)
+            self._per_env_clock = True
+            self._wind_env = state.get("wind_env")
+            sh.upload_state(L.B_SCREEN, state["screen"], st)
+            sh.set_clock_env(clk)
+        else:
+            if self._per_env_clock:
+                raise ValueError("this env runs per-env clocks; the state was saved from a shared-clock env")
+            self._push_wind(reset=False)
+            sh.upload_state(L.B_SCREEN, state["screen"], st)
+            sh.set_buff(state["buff"])
         sh.upload_state(L.B_MT_STATE, state["mt"], st, dtype=np.uint32)
         sh.upload_state(L.B_COEFS, state["coefs"], st)
         sh.upload_state(L.B_DM_PREV, state.get("dm_prev", state["coefs"]), st)
