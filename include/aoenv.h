@@ -181,6 +181,11 @@ int aoenv_set_coefs(AoEnv* env, const double* h_coefs, void* stream);
  * 476-485): residual phase = (atm.OPD_no_pupil + dm.OPD) * pupil, WFS measurement, signal. */
 int aoenv_measure(AoEnv* env, void* stream);
 
+/* Replaces: atm.update() on its own (OOPAO/Atmosphere.py:439-477; the open-loop scripts call it between propagations):
+ * every layer moves by one frame -- ring extrusions included -- and atm.OPD_no_pupil (AOENV_B_OPD_ATM) and the residual
+ * phase are re-derived.  No WFS measurement, no controller.  aoenv_step = this + aoenv_measure + the glue. */
+int aoenv_atm_update(AoEnv* env, void* stream);
+
 /* Replaces: env.reset_soft() (MAIN/OOPAOEnv/OOPAOEnv.py:82-86): obs = vec_to_img(-R @ wfs.signal) * 1e6.
  * d_obs [n_env][n_act][n_act]. */
 int aoenv_reset_soft(AoEnv* env, void* d_obs, void* stream);

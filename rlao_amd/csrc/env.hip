@@ -836,6 +836,13 @@ struct DeviceGuard {
     if (!(env)) return fail("null AoEnv");                                            \
     DeviceGuard ao_device_guard((env)->device);                                       \
     if (!ao_device_guard.ok) return fail("hipSetDevice(%d) failed", (env)->device)
+template <typename T>
+int atm_update_t(AoEnv* env, hipStream_t st) {
+    AO_TRY(advance_atmosphere<T>(env, false, st));
+    env->atm_user_defined = false;
+    return run_phase<T>(env, 1, 1, st);
+}
+
 #define AO_DISPATCH(env, fn, ...) ((env)->c.dtype == AOENV_F32 ? fn<float>(__VA_ARGS__) : fn<double>(__VA_ARGS__))
 
 extern "C" {
@@ -1497,6 +1504,13 @@ int aoenv_measure(AoEnv* env, void* stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     AO_TRY(AO_DISPATCH(env, run_phase, env, 1, 1, st));            // atmosphere re-derived from the screens at the current buff
     return AO_DISPATCH(env, run_wfs, env, st);
+}
+
+int aoenv_atm_update(AoEnv* env, void* stream) {
+    AO_CHECK_ENV(env);
+    AO_TRY(require_step_constants(env, true));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    return AO_DISPATCH(env, atm_update_t, env, st);
 }
 
 int aoenv_reset_soft(AoEnv* env, void* d_obs, void* stream) {

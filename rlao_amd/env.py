@@ -89,6 +89,9 @@ class Shard:
     def measure(self, stream=0):
         L.check(self.lib.aoenv_measure(self.h, C.c_void_p(stream)))
 
+    def atm_update(self, stream=0):
+        L.check(self.lib.aoenv_atm_update(self.h, C.c_void_p(stream)))
+
     def download(self, which: int, shape, stream=0, dtype=None) -> np.ndarray:
         out = np.empty(shape, dtype=self.np_dtype if dtype is None else dtype)
         L.check(self.lib.aoenv_download(self.h, which, out.ctypes.data_as(C.c_void_p), out.nbytes, C.c_void_p(stream)))
@@ -197,7 +200,8 @@ class _AtmProxy:
         self._e.generate_new_phase_screen(seed)
 
     def update(self):
-        raise NotImplementedError("atm.update() outside env.step() is not part of the hot-path surface")
+        """atm.update() (OOPAO/Atmosphere.py:439-477): every layer of every env one frame on; atm.OPD_no_pupil follows."""
+        self._e._shard.atm_update(self._e._stream())
 
     @property
     def OPD_no_pupil(self):

@@ -136,3 +136,32 @@ def test_per_env_wind_matches_oracle_and_survives_checkpoint_and_new_episode():
     for x, y in zip(a, c):
         assert torch.equal(x[0][2], y[0][2]) and torch.equal(y[0][0], y[0][2])     # every env now has env 2's wind
     env.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_atm_update_alone_moves_the_atmosphere_like_a_step(dtype):
+    """atm.update() (OOPAO/Atmosphere.py:439-477) without the rest of env.step(): 15 updates == 15 steps with a zero command, as far
+    as the atmosphere goes (atm.OPD_no_pupil bit for bit; the steps run the fused kernel in float32, the update the batched one)."""
+    import torch
+    from rlao_amd import _lib as L
+    a, b = _make(3, dtype), _make(3, dtype)
+    L.check(b._shard.lib.aoenv_set_option(b._shard.h, L.OPT_STORE_ATM_OPD, 1))
+    for env in (a, b):
+        env.env_seed_stride = 1
+        env.atm.windSpeed = [25.0]                                  # 0.75 px per frame: ~11 ring extrusions
+        env.generate_new_phase_screen(4)
+        env.dm.coefs = 0
+        env.dm_prev = 0
+        env.measure()
+    zero = torch.zeros_like(b.reset_soft())
+    for i in range(15):
+        a.atm.update()
+        b.step(i, zero)
+    oa, ob = a.atm.OPD_no_pupil, b.atm.OPD_no_pupil
+    assert np.array_equal(oa, ob) and np.abs(oa).max() > 0 and not np.array_equal(oa[0], oa[1])
+    a.measure()                                                     # tel*dm*wfs after the updates: the frame of the 15th step
+    fa = a._shard.download(L.B_FRAME, (3, a.cam_res, a.cam_res))
+    fb = b._shard.download(L.B_FRAME, (3, b.cam_res, b.cam_res))
+    np.testing.assert_allclose(fa, fb, atol=(0 if dtype == "f64" else 2e-5) * fb.max())   # (float32: batched vs fused kernels)
+    a.close()
+    b.close()
