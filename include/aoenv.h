@@ -270,12 +270,12 @@ enum AoOption {
                                  0 (default below): every tile workgroup does it itself */
     AOENV_OPT_FACTORED_RECON = 8, /* 1 (default): with AOENV_C_RECON_FACTORS uploaded, the batched (non-fused) reconstruction is the
                                  chained product v = M2C (M s) instead of the dense reconstructor; 0: dense */
-    AOENV_OPT_RING_LOOKAHEAD = 9, /* 1: float32 fused step: the ring extrusion of a layer's next pixel crossing (Z gather, MT19937 innovations,
-                                 X = [A | B] [Z; xi]) is computed right after the previous crossing on a second stream, and the crossing
-                                 step only waits for its event.  0 (default): in front of the crossing step, on the caller's stream --
-                                 measured FASTER at one workgroup per CU (256 envs): the step kernel fills every CU (LDS and registers),
-                                 so the side stream's workgroups only run between two step kernels and delay the next one's workgroups on
-                                 the CUs they take (5.59 -> 4.97 M env-steps/s); it pays only while CUs are idle (< 256 envs per GPU) */
+    AOENV_OPT_RING_LOOKAHEAD = 9, /* 1 (default): float32 fused step, shared clock: the ring pipeline -- the operand [Z | xi] of a layer's NEXT
+                                 pixel crossing is put together while the current one is served: xi by extra workgroups of the ring GEMM's
+                                 launch, Z by the step kernel once it has written the ring; a crossing step then launches the GEMM and
+                                 nothing else in front of the step kernel (bit-identical results).  0: gather + draw in a launch of
+                                 their own in front of the GEMM.  [Round-2 note: the same work one crossing ahead on a SECOND STREAM was
+                                 slower -- with one 1024-lane workgroup per CU the side stream finds no free CU (5.59 -> 4.97 M env-steps/s)] */
     AOENV_OPT_FAST_TRIG = 2  /* 1 (default): v_sin/v_cos after Cody-Waite reduction in the float32 SH kernel; 0: sincosf */
 };
 int aoenv_set_option(AoEnv* env, int option, int value);

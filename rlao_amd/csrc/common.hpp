@@ -133,6 +133,17 @@ int launch_ring_prepare_env(const T* map, T* zx, const int* inner_idx, uint32_t*
 template <typename T>
 int launch_minmax(const T* maps, T* minmax, int n_env, int S, hipStream_t st);
 int gemm_splits(int M, int N, int K);
+// the draw of a layer's next innovations, run beside the ring GEMM (k_ring_gemm_draw_ahead)
+struct MtAhead {
+    const uint32_t* mt_in;   // [n_env][624] committed stream
+    const int* pos_in;
+    uint32_t* mt_out;        // the stream after the draw (another buffer)
+    int* pos_out;
+    float* zx_out;           // [n_env][K]: the draw goes to columns n_inner ..
+    int K, n_inner, n_outer, n_env;
+};
+int launch_ring_gemm_draw_ahead(const float* X, const float* W, float* Cpart, int M, int N, int K, int splits, const MtAhead& m,
+                                hipStream_t st);
 int launch_gemm_nt_mfma(const float* X, const float* W, float* Cpart, int M, int N, int K, int ldx, int ldw, int splits,
                         hipStream_t st, int xsplits = 1, size_t xslab = 0);
 template <typename T>
@@ -266,6 +277,11 @@ struct StepArgs {
     int ring_splits[kMaxLayer];
     const int* outer_idx;        // [n_outer] logical flat index of every ring pixel
     int n_outer;
+    // ... and the Z of the layer's NEXT crossing, gathered here once the ring is in place (the screen does not change until then):
+    float* next_zx[kMaxLayer];   // [E][zx_ld] operand of the next ring GEMM (columns 0 .. n_inner), null = not asked for
+    int next_sx[kMaxLayer], next_sy[kMaxLayer];   // direction of that crossing
+    const int* inner_idx;        // [n_inner]
+    int n_inner, zx_ld;
     int n_modes, n_subap, n_valid, n_env;
 };
 int step_fused_supported(int R, int n_subap, int n_valid, int n_act, int n_modes);

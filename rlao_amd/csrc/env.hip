@@ -60,18 +60,19 @@ struct AoEnv {
     int* pos_cur[kMaxLayer] = {nullptr};
     uint32_t* mt_alt[kMaxLayer] = {nullptr};   // ... and the other copy (swapped in when a look-ahead is consumed)
     int* pos_alt[kMaxLayer] = {nullptr};
-    // Ring look-ahead (float32 fused path): the extrusion X = A Z + B xi of a layer's NEXT pixel crossing does not depend on the
-    // steps in between (the screen only changes at crossings, the stream position too), so it is computed right after the
-    // previous crossing on a second stream and the crossing step only waits for an event: k_ring_prepare + the ring GEMM
-    // (19 us, on a third of the steps) leave the critical path.
-    struct RingAhead { bool valid = false; int sx = 0, sy = 0, splits = 0; hipEvent_t ready = nullptr; };
+    // Ring pipeline (float32 fused path, shared clock): the operand [Z | xi] of a layer's NEXT pixel crossing is put together while
+    // the current crossing is being served -- xi by extra workgroups of the ring GEMM's launch (the stream position only moves at
+    // crossings), Z by the fused step kernel right after it has written the ring (the screen does not change until the next
+    // crossing) -- so a crossing step launches the GEMM and nothing else in front of the step kernel: k_ring_prepare (9 us, the
+    // Gaussian draw) leaves the critical path.  [An earlier form ran prepare + GEMM one crossing ahead on a second stream: with one
+    // 1024-lane workgroup resident on every CU the side-stream kernels found no free CU and time-sliced with the step kernel: slower.]
+    struct RingAhead { bool valid = false; int sx = 0, sy = 0, buf = 0; };   // zx_pipe[buf][l] holds [Z | xi] for a crossing in direction (sx, sy); mt_alt[l] the stream after it
     RingAhead ahead[kMaxLayer];
-    hipStream_t side = nullptr;             // the look-ahead's stream
-    hipEvent_t ev_main = nullptr;           // "the step kernel that wrote the last ring is done" (recorded on the caller's stream)
-    void* zx_ahead = nullptr;               // [L][E][K]
-    void* xbuf_ahead = nullptr;             // [L][splits][E][nout]
-    const void* ring_src[kMaxLayer] = {nullptr};   // slabs of the pending (deferred) ring of every layer: xbuf or xbuf_ahead
-    bool use_lookahead = false;             // aoenv_set_option(AOENV_OPT_RING_LOOKAHEAD): off by default, see aoenv.h
+    bool gather_next[kMaxLayer] = {false};  // the next fused step kernel is to gather Z into zx_pipe[ahead.buf][l]
+    void* zx_pipe = nullptr;                // [2][L][E][K]
+    const void* last_zx = nullptr;          // operand of the last ring GEMM (AOENV_B_XI)
+    const void* ring_src[kMaxLayer] = {nullptr};   // slabs of the pending (deferred) ring of every layer
+    bool use_lookahead = true;              // aoenv_set_option(AOENV_OPT_RING_LOOKAHEAD): the ring pipeline
     void* zx = nullptr;                     // [E][K]  [Z | xi]
     void* xbuf = nullptr;                   // [splits][E][nout] split-K slabs of the ring GEMM
     void* ab = nullptr;                     // [nout][K]
@@ -153,8 +154,7 @@ struct AoEnv {
     }
     void* minmax_ptr(int l) const { return static_cast<char*>(minmax) + (size_t)l * E * 2 * esz; }
     void* xbuf_ptr(int l) const { return static_cast<char*>(xbuf) + (size_t)l * kMaxSplits * E * nout * esz; }
-    void* xbuf_ahead_ptr(int l) const { return static_cast<char*>(xbuf_ahead) + (size_t)l * kMaxSplits * E * nout * esz; }
-    void* zx_ahead_ptr(int l) const { return static_cast<char*>(zx_ahead) + (size_t)l * E * K * esz; }
+    void* zx_pipe_ptr(int buf, int l) const { return static_cast<char*>(zx_pipe) + ((size_t)buf * L + l) * E * K * esz; }
 };
 
 namespace {
@@ -250,11 +250,25 @@ int gemm_dispatch<double>(AoEnv*, const double* X, const double* W, double* C, i
     return launch_gemm_nt<double>(X, W, C, M, N, K, K, K, N, st);
 }
 
+// The operand prepared for a layer's next crossing will not be used (the screens, the stream or the wind changed): nothing of it
+// was committed -- the stream copy it advanced is the alternate one -- so it is simply forgotten; the crossing draws in place.
+int drop_lookahead(AoEnv* env, int l, hipStream_t) {
+    env->ahead[l].valid = false;
+    env->gather_next[l] = false;
+    return 0;
+}
+int drop_lookaheads(AoEnv* env, hipStream_t st) {
+    for (int l = 0; l < env->L; ++l) AO_TRY(drop_lookahead(env, l, st));
+    return 0;
+}
+int sync_lookaheads(AoEnv* env) { return drop_lookaheads(env, nullptr); }
+
 // ---- add_row on the device (OOPAO/Atmosphere.py:301-311) for every env of the shard ---------------
 // lean = true: the ring is scattered without the min / max pass; the fused step kernel recomputes the range from the map
 template <typename T>
 int flush_ring(AoEnv* env, int l, hipStream_t st) {
     if (!env->ring_pending[l]) return 0;
+    if (env->gather_next[l]) AO_TRY(drop_lookahead(env, l, st));   // (the step kernel that would have gathered the next Z is not coming)
     AO_PROF(env, SCATTER, st);
     // (per-env clocks: only the envs that crossed, each through its own origin, and their range right away -- there is no
     //  per-env "dirty" flag on the host)
@@ -271,26 +285,6 @@ int flush_rings(AoEnv* env, hipStream_t st) {
     return 0;
 }
 
-// Host-synchronous invalidation of every look-ahead (the screens, the streams or the operators are about to be replaced from the host)
-int sync_lookaheads(AoEnv* env) {
-    if (!env->side) return 0;
-    AO_HIP(hipStreamSynchronize(env->side));
-    for (int l = 0; l < env->L; ++l) env->ahead[l].valid = false;
-    return 0;
-}
-
-// A look-ahead that will not be used (its inputs changed): nothing of it was committed -- the stream copy it advanced is the
-// alternate one, its slabs are scratch -- but the caller's stream must not reuse those buffers before it has finished.
-int drop_lookahead(AoEnv* env, int l, hipStream_t st) {
-    if (!env->ahead[l].valid) return 0;
-    env->ahead[l].valid = false;
-    AO_HIP(hipStreamWaitEvent(st, env->ahead[l].ready, 0));
-    return 0;
-}
-int drop_lookaheads(AoEnv* env, hipStream_t st) {
-    for (int l = 0; l < env->L; ++l) AO_TRY(drop_lookahead(env, l, st));
-    return 0;
-}
 
 // lean: no min / max pass (the fused step kernel recomputes the range from the map);  defer: not even the scatter -- the
 // fused step kernel of this step writes the ring itself (one launch less per crossing)
@@ -316,6 +310,7 @@ int extrude(AoEnv* env, int l, int sx, int sy, bool lean, hipStream_t st, bool d
     // the shift itself: move the origin of the torus
     env->org[l][0] = ((oy - sy) % S + S) % S;
     env->org[l][1] = ((ox - sx) % S + S) % S;
+    env->last_zx = zx;
     if (defer && lean) {
         env->ring_pending[l] = splits;
         env->ring_src[l] = env->xbuf_ptr(l);
@@ -341,6 +336,67 @@ int refresh_minmax(AoEnv* env, hipStream_t st) {
 }
 
 // ---- atm.update(): host clock of updateLayer (OOPAO/Atmosphere.py:350-407) -----------------------
+// The direction of a layer's next sub-pixel crossing, by running its clock forward (same arithmetic as advance_atmosphere).
+bool next_crossing(const LayerClock& k0, int* sx, int* sy) {
+    if ((int)std::fabs(k0.ratio[0]) > 0 || (int)std::fabs(k0.ratio[1]) > 0) return false;   // whole-pixel shifts every step: no look-ahead
+    if (k0.ratio[0] == 0 && k0.ratio[1] == 0) return false;
+    double b[2] = {k0.buff[0], k0.buff[1]};
+    for (int it = 0; it < 1000000; ++it) {
+        for (int d = 0; d < 2; ++d) b[d] += std::fmod(std::fabs(k0.ratio[d]), 1.0) * sgn(k0.ratio[d]);
+        if (std::fabs(b[0]) >= 1 || std::fabs(b[1]) >= 1) {
+            *sx = std::fabs(b[0]) < 1 ? 0 : (int)sgn(b[0]);
+            *sy = std::fabs(b[1]) < 1 ? 0 : (int)sgn(b[1]);
+            return true;
+        }
+        for (int d = 0; d < 2; ++d) b[d] = std::fmod(std::fabs(b[d]), 1.0) * sgn(b[d]);
+    }
+    return false;
+}
+
+// A crossing of the float32 fused path through the ring pipeline (AoEnv::RingAhead): if the operand [Z | xi] of this crossing was
+// put together ahead, commit its stream copy and launch the GEMM alone; else prepare it in place as extrude() does.  Either way
+// the GEMM's launch also draws the innovations of the NEXT crossing, and the step kernel of this step is asked to gather its Z.
+// The ring itself is left to that kernel (deferred scatter).  Bit-identical to extrude(): the same Z, the same xi, the same product.
+int extrude_pipelined(AoEnv* env, int l, int sx, int sy, hipStream_t st) {
+    AoEnv::RingAhead& ah = env->ahead[l];
+    const int S = env->S, oy = env->org[l][0], ox = env->org[l][1];
+    const int cur = ah.buf;
+    float* op = static_cast<float*>(env->zx_pipe_ptr(cur, l));
+    if (ah.valid && ah.sx == sx && ah.sy == sy) {
+        std::swap(env->mt_cur[l], env->mt_alt[l]);                 // the draw made ahead becomes the layer's stream
+        std::swap(env->pos_cur[l], env->pos_alt[l]);
+    } else {
+        AO_PROF(env, SHIFT_GATHER, st);
+        AO_TRY(launch_ring_prepare<float>(env->as<float>(env->screen_ptr(0, l)), op, env->inner_idx, env->mt_cur[l], env->pos_cur[l],
+                                          env->mt_cur[l], env->pos_cur[l], env->E, S, env->nin, env->nout, env->K, sx, sy, oy, ox, st));
+    }
+    ah.valid = false;
+    env->gather_next[l] = false;
+    const int splits = gemm_splits(env->E, env->nout, env->K);
+    MtAhead m{env->mt_cur[l], env->pos_cur[l], env->mt_alt[l], env->pos_alt[l], static_cast<float*>(env->zx_pipe_ptr(1 - cur, l)),
+              env->K, env->nin, env->nout, env->E};
+    {
+        AO_PROF(env, GEMM_RING, st);
+        AO_TRY(launch_ring_gemm_draw_ahead(op, env->as<float>(env->ab), static_cast<float*>(env->xbuf_ptr(l)), env->E, env->nout, env->K,
+                                           splits, m, st));
+    }
+    env->last_zx = op;
+    env->org[l][0] = ((oy - sy) % S + S) % S;                      // the shift itself: move the origin of the torus
+    env->org[l][1] = ((ox - sx) % S + S) % S;
+    env->ring_pending[l] = splits;
+    env->ring_src[l] = env->xbuf_ptr(l);
+    env->minmax_dirty[l] = true;
+    int nsx = 0, nsy = 0;
+    if (next_crossing(env->clk[l], &nsx, &nsy)) {                   // (the clock has been advanced for this step already)
+        ah.valid = true;
+        ah.sx = nsx;
+        ah.sy = nsy;
+        ah.buf = 1 - cur;
+        env->gather_next[l] = true;
+    }
+    return 0;
+}
+
 // Per-env clocks: one launch per layer advances every env's clock on the device and prepares [Z | xi] of the envs that cross a
 // pixel; the ring GEMM runs over the whole shard (rows of the other envs are computed and never used: which envs cross is
 // not known on the host, and with independent winds some env crosses on nearly every step anyway).
@@ -362,6 +418,7 @@ int advance_atmosphere_env(AoEnv* env, bool lean, hipStream_t st) {
             AO_PROF(env, GEMM_RING, st);
             AO_TRY(gemm_dispatch<T>(env, zx, env->as<T>(env->ab), env->as<T>(env->xbuf_ptr(l)), env->E, env->nout, env->K, &splits, st));
         }
+        env->last_zx = zx;
         env->ring_pending[l] = splits;
         env->ring_src[l] = env->xbuf_ptr(l);
         if (!(lean && env->defer_ring)) AO_TRY(flush_ring<T>(env, l, st));
@@ -384,19 +441,8 @@ int advance_atmosphere(AoEnv* env, bool lean, hipStream_t st) {
             AO_TRY(extrude<T>(env, l, ns[0] == mn ? 0 : s0, ns[1] == mn ? 0 : s1, lean, st));
         int b0, b1;
         if (clock_subpixel(k.ratio, k.buff, &b0, &b1)) {          // (the arithmetic the per-env device clocks share, common.hpp)
-            AoEnv::RingAhead& ah = env->ahead[l];
-            if (lean && env->defer_ring && ah.valid && ah.sx == b0 && ah.sy == b1 && !env->ring_pending[l]) {
-                // the extrusion of this crossing was computed ahead: wait for it, commit its stream copy, move the torus origin
-                AO_HIP(hipStreamWaitEvent(st, ah.ready, 0));
-                ah.valid = false;
-                std::swap(env->mt_cur[l], env->mt_alt[l]);
-                std::swap(env->pos_cur[l], env->pos_alt[l]);
-                const int S = env->S;
-                env->org[l][0] = ((env->org[l][0] - b1) % S + S) % S;
-                env->org[l][1] = ((env->org[l][1] - b0) % S + S) % S;
-                env->ring_pending[l] = ah.splits;
-                env->ring_src[l] = env->xbuf_ahead_ptr(l);
-                env->minmax_dirty[l] = true;
+            if (lean && env->defer_ring && env->use_lookahead && env->zx_pipe && !env->ring_pending[l]) {
+                AO_TRY(extrude_pipelined(env, l, b0, b1, st));
             } else {
                 AO_TRY(extrude<T>(env, l, b0, b1, lean, st, lean && env->defer_ring));
             }
@@ -627,60 +673,6 @@ void fill_phase_args(AoEnv* env, PhaseArgs& pa, PhaseBuffers<T>& pb, int update_
     pb.wfs_max = env->as<T>(env->wfs_max);
 }
 
-// The direction of a layer's next sub-pixel crossing, by running its clock forward (same arithmetic as advance_atmosphere).
-static bool next_crossing(const LayerClock& k0, int* sx, int* sy) {
-    if ((int)std::fabs(k0.ratio[0]) > 0 || (int)std::fabs(k0.ratio[1]) > 0) return false;   // whole-pixel shifts every step: no look-ahead
-    if (k0.ratio[0] == 0 && k0.ratio[1] == 0) return false;
-    double b[2] = {k0.buff[0], k0.buff[1]};
-    for (int it = 0; it < 1000000; ++it) {
-        for (int d = 0; d < 2; ++d) b[d] += std::fmod(std::fabs(k0.ratio[d]), 1.0) * sgn(k0.ratio[d]);
-        if (std::fabs(b[0]) >= 1 || std::fabs(b[1]) >= 1) {
-            *sx = std::fabs(b[0]) < 1 ? 0 : (int)sgn(b[0]);
-            *sy = std::fabs(b[1]) < 1 ? 0 : (int)sgn(b[1]);
-            return true;
-        }
-        for (int d = 0; d < 2; ++d) b[d] = std::fmod(std::fabs(b[d]), 1.0) * sgn(b[d]);
-    }
-    return false;
-}
-
-// After a fused step: for every layer without one, compute the ring extrusion of its next crossing on the side stream.  It reads
-// the screen as this step's kernel leaves it (ring of this step included) and the committed stream copy, and writes the slabs
-// X = [A | B] [Z; xi] and the advanced stream to buffers of its own; the crossing step commits them (advance_atmosphere).
-static int launch_lookaheads(AoEnv* env, hipStream_t st) {
-    if (!env->use_lookahead || !env->side || !env->defer_ring) return 0;
-    bool recorded = false;
-    for (int l = 0; l < env->L; ++l) {
-        AoEnv::RingAhead& ah = env->ahead[l];
-        int sx = 0, sy = 0;
-        if (ah.valid || !next_crossing(env->clk[l], &sx, &sy)) continue;
-        if (!recorded) {
-            AO_HIP(hipEventRecord(env->ev_main, st));
-            AO_HIP(hipStreamWaitEvent(env->side, env->ev_main, 0));
-            recorded = true;
-        }
-        float* zx = static_cast<float*>(env->zx_ahead_ptr(l));
-        {
-            AO_PROF(env, SHIFT_GATHER, env->side);
-            AO_TRY(launch_ring_prepare<float>(env->as<float>(env->screen_ptr(0, l)), zx, env->inner_idx, env->mt_cur[l], env->pos_cur[l],
-                                              env->mt_alt[l], env->pos_alt[l], env->E, env->S, env->nin, env->nout, env->K, sx, sy,
-                                              env->org[l][0], env->org[l][1], env->side));
-        }
-        int splits = 1;
-        {
-            AO_PROF(env, GEMM_RING, env->side);
-            AO_TRY(gemm_dispatch<float>(env, zx, env->as<float>(env->ab), static_cast<float*>(env->xbuf_ahead_ptr(l)), env->E, env->nout,
-                                        env->K, &splits, env->side));
-        }
-        AO_HIP(hipEventRecord(ah.ready, env->side));
-        ah.valid = true;
-        ah.sx = sx;
-        ah.sy = sy;
-        ah.splits = splits;
-    }
-    return 0;
-}
-
 template <typename T>
 int run_fused_step(AoEnv*, int, const void*, void*, void*, void*, double, hipStream_t) { return fail("fused step: float32 only"); }
 template <>
@@ -721,6 +713,17 @@ int run_fused_step<float>(AoEnv* env, int i, const void* d_action, void* d_obs, 
     }
     a.outer_idx = env->outer_idx;
     a.n_outer = env->nout;
+    for (int l = 0; l < env->L; ++l) {
+        const bool g = env->gather_next[l] && env->ring_pending[l] && env->ahead[l].valid;
+        a.next_zx[l] = g ? static_cast<float*>(env->zx_pipe_ptr(env->ahead[l].buf, l)) : nullptr;
+        a.next_sx[l] = env->ahead[l].sx;
+        a.next_sy[l] = env->ahead[l].sy;
+        if (env->gather_next[l] && !g) env->ahead[l].valid = false;
+        env->gather_next[l] = false;
+    }
+    a.inner_idx = env->inner_idx;
+    a.n_inner = env->nin;
+    a.zx_ld = env->K;
     a.n_modes = env->n_modes;
     a.n_subap = env->nSub;
     a.n_valid = env->nVal;
@@ -731,7 +734,7 @@ int run_fused_step<float>(AoEnv* env, int i, const void* d_action, void* d_obs, 
     }
     for (int l = 0; l < env->L; ++l) env->minmax_dirty[l] = false;   // the kernel recomputed and stored them
     for (int l = 0; l < env->L; ++l) env->ring_pending[l] = 0;        // ... and wrote the deferred rings
-    return launch_lookaheads(env, st);
+    return 0;
 }
 
 template <typename T>
@@ -808,7 +811,7 @@ int buf_info(AoEnv* env, int which, BufInfo* b) {
         case AOENV_B_TOTAL: *b = {env->total, (size_t)env->c.n_loop * E * z}; return 0;
         case AOENV_B_RESIDUAL: *b = {env->residual, (size_t)env->c.n_loop * E * z}; return 0;
         case AOENV_B_WFS_MAX: *b = {env->wfs_max, E * z}; return 0;
-        case AOENV_B_XI: *b = {env->zx, E * env->K * z}; return 0;
+        case AOENV_B_XI: *b = {env->last_zx ? const_cast<void*>(env->last_zx) : env->zx, E * env->K * z}; return 0;
         case AOENV_B_MT_STATE: *b = {nullptr, (size_t)env->L * E * (kMtN + 1) * 4}; return 0;     // packed on the host
         case AOENV_B_COUNTERS: *b = {nullptr, 16}; return 0;
         case AOENV_B_DM_PREV: *b = {env->dm_prev, E * env->A * z}; return 0;
@@ -894,9 +897,8 @@ int aoenv_create(const AoCfg* cfg, int device, AoEnv** out) {
         A_(&e->minmax, (size_t)e->L * E * 2 * z);
         A_((void**)&e->mt_state, (size_t)2 * e->L * E * kMtN * 4);
         A_((void**)&e->mt_pos, (size_t)2 * e->L * E * 4);
-        if (cfg->dtype == AOENV_F32) {                              // ring look-ahead (fused float32 path)
-            A_(&e->zx_ahead, (size_t)e->L * E * e->K * z);
-            A_(&e->xbuf_ahead, (size_t)e->L * kMaxSplits * E * e->nout * z);
+        if (cfg->dtype == AOENV_F32) {                              // ring pipeline (fused float32 path)
+            A_(&e->zx_pipe, (size_t)2 * e->L * E * e->K * z);
         }
         A_(&e->zx, E * e->K * z);
         A_(&e->xbuf, (size_t)e->L * kMaxSplits * E * e->nout * z);
@@ -957,13 +959,6 @@ int aoenv_create(const AoCfg* cfg, int device, AoEnv** out) {
         e->pos_cur[l] = e->mt_pos + (size_t)l * E;
         e->pos_alt[l] = e->mt_pos + (size_t)(e->L + l) * E;
     }
-    if (e->zx_ahead) {
-        bool ok = hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) == hipSuccess &&
-                  hipEventCreateWithFlags(&e->ev_main, hipEventDisableTiming) == hipSuccess;
-        for (int l = 0; l < e->L && ok; ++l) ok = hipEventCreateWithFlags(&e->ahead[l].ready, hipEventDisableTiming) == hipSuccess;
-        if (!ok) { aoenv_destroy(e); return fail("could not create the look-ahead stream / events"); }
-    }
-
     // DFT twiddles w^k = exp(-2 pi i k / n) and the centring phasor exp(-i pi (n+1)/n x) at x = a + lo
     // (OOPAO/ShackHartmann.py:208-209), in float64 then converted
     if (cfg->wfs_type == AOENV_WFS_SH) {
@@ -995,10 +990,6 @@ int aoenv_create(const AoCfg* cfg, int device, AoEnv** out) {
 int aoenv_destroy(AoEnv* env) {
     if (!env) return 0;
     DeviceGuard ao_device_guard(env->device);
-    if (env->side) { (void)hipStreamSynchronize(env->side); (void)hipStreamDestroy(env->side); }
-    if (env->ev_main) (void)hipEventDestroy(env->ev_main);
-    for (int l = 0; l < kMaxLayer; ++l)
-        if (env->ahead[l].ready) (void)hipEventDestroy(env->ahead[l].ready);
     for (auto& e : env->prof_ev) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (void* p : env->allocs) (void)hipFree(p);
     delete env;
@@ -1236,7 +1227,6 @@ int aoenv_set_wind_env(AoEnv* env, const double* h_ratio, int reset_buff, void* 
         if (reset_buff) clk[i].buff[0] = clk[i].buff[1] = 0;
     }
     env->per_env_wind = true;
-    env->use_lookahead = false;
     return push_env_clocks(env, clk);
 }
 

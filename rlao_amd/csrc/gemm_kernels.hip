@@ -4,6 +4,7 @@
 //   dm.OPD = modes @ coefs  OOPAO/DeformableMirror.py:556 (dense-DM path)
 // All three are "NT" products  C[M][N] = X[M][K] . W[N][K]^T  with M = n_env and W shared by every env.
 #include "common.hpp"
+#include "ring_device.hpp"
 
 namespace ao {
 
@@ -80,14 +81,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // xsplits > 1: X is itself a stack of split-K slabs X[z][M][ldx] (z < xsplits, xslab floats apart) of an earlier product; they are
 // summed in slab order while the operand is staged (chained products, e.g. v = M2C (M s), need no reduction launch in between).
-__global__ void __launch_bounds__(256) k_gemm_nt_mfma(const float* __restrict__ X, const float* __restrict__ W,
-                                                      float* __restrict__ Cpart, int M, int N, int K, int ldx,
-                                                      int ldw, int kslice, int xsplits, size_t xslab) {
+__device__ inline void gemm_nt_mfma_tile(const float* __restrict__ X, const float* __restrict__ W, float* __restrict__ Cpart, int M,
+                                         int N, int K, int ldx, int ldw, int kslice, int xsplits, size_t xslab, int bz) {
     constexpr int BM = 64, BN = 64, BK = 32, LDT = BK + 1;
     __shared__ float xs[BM * LDT];
     __shared__ float ws[BN * LDT];
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int kbeg = blockIdx.z * kslice, kend = min(K, kbeg + kslice);
+    const int kbeg = bz * kslice, kend = min(K, kbeg + kslice);
     const int wave = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
     const int lr = lane & 31, lh = lane >> 5;
@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(256) k_gemm_nt_mfma(const float* __restrict__ 
         __syncthreads();
     }
     // C/D map of the 32x32 shape: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-    float* C = Cpart + (size_t)blockIdx.z * M * N;
+    float* C = Cpart + (size_t)bz * M * N;
     const int gn = n0 + wn + lr;
     if (gn < N) {
 #pragma unroll
@@ -161,6 +161,40 @@ __global__ void __launch_bounds__(256) k_gemm_nt_mfma(const float* __restrict__ 
             if (gm < M) C[(size_t)gm * N + gn] = acc[rg];
         }
     }
+}
+
+__global__ void __launch_bounds__(256) k_gemm_nt_mfma(const float* __restrict__ X, const float* __restrict__ W,
+                                                      float* __restrict__ Cpart, int M, int N, int K, int ldx,
+                                                      int ldw, int kslice, int xsplits, size_t xslab) {
+    gemm_nt_mfma_tile(X, W, Cpart, M, N, K, ldx, ldw, kslice, xsplits, xslab, (int)blockIdx.z);
+}
+
+// The ring GEMM X = [Z | xi] [A | B]^T with the NEXT crossing's innovations drawn beside it: the z-slices beyond `splits` are
+// not slices of the product but one workgroup per env running the layer's MT19937 stream one draw ahead (mt_normal_body,
+// out of place: the caller commits the advanced stream at the next crossing).  Both kinds of workgroup are small -- a CU holds
+// several of each -- so the 9 us of the Gaussian draw, serial in front of the product before, now hide behind it.
+__global__ void __launch_bounds__(256) k_ring_gemm_draw_ahead(const float* __restrict__ X, const float* __restrict__ W,
+                                                              float* __restrict__ Cpart, int M, int N, int K, int ldx, int ldw,
+                                                              int kslice, int splits, const MtAhead m) {
+    // the draws first (lowest workgroup ids: dispatched first): they are the longer of the two kinds
+    const int draw_slices = (int)gridDim.z - splits;
+    if ((int)blockIdx.z >= draw_slices) {
+        gemm_nt_mfma_tile(X, W, Cpart, M, N, K, ldx, ldw, kslice, 1, 0, (int)blockIdx.z - draw_slices);
+        return;
+    }
+    const int e = ((int)blockIdx.z * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + (int)blockIdx.x;
+    if (e < m.n_env) mt_normal_body<float>(m.mt_in, m.pos_in, m.mt_out, m.pos_out, m.zx_out, m.K, m.n_inner, m.n_outer, e);
+}
+
+int launch_ring_gemm_draw_ahead(const float* X, const float* W, float* Cpart, int M, int N, int K, int splits, const MtAhead& m,
+                                hipStream_t st) {
+    if (m.n_outer % 2) return fail("mt_normal: n_outer=%d must be even", m.n_outer);
+    const int kslice = cdiv(cdiv(K, splits), 32) * 32;
+    const int gx = cdiv(N, 64), gy = cdiv(M, 64);
+    dim3 grid(gx, gy, splits + cdiv(m.n_env, gx * gy));
+    hipLaunchKernelGGL(k_ring_gemm_draw_ahead, grid, dim3(256), 0, st, X, W, Cpart, M, N, K, K, K, kslice, splits, m);
+    AO_HIP(hipGetLastError());
+    return 0;
 }
 
 int gemm_splits(int M, int N, int K) {

@@ -34,6 +34,7 @@ namespace ao { __device__ unsigned long long g_stamps[1024 * 32]; __device__ uns
 
 #include "sh_device.hpp"
 #include "detector.hpp"
+#include "ring_device.hpp"
 
 // diagnostic ablation of the camera block (scripts/diag_cam_ablate.sh): -DAO_CAM_ABLATE=<bit mask>; wrong frames, timing only
 #ifdef AO_CAM_ABLATE
@@ -225,6 +226,13 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
             }
         }
         if (any) __syncthreads();                                // s_waitcnt vmcnt(0) lgkmcnt(0) + barrier: stores acknowledged
+        // Z of the layer's next crossing (env.hip: ring pipeline): the two rings inside the new border, through the new origin
+        if (!PE) {
+            for (int l = 0; l < k.pa.n_layer; ++l)
+                if (a.next_zx[l] != nullptr)
+                    gather_ring<float>(static_cast<const float*>(k.pa.screen[l]), a.next_zx[l], a.inner_idx, S, a.n_inner, a.zx_ld,
+                                       a.next_sx[l], a.next_sy[l], k.pa.taps[l].oy, k.pa.taps[l].ox, e, tid, 1024);
+        }
     }
 
     // ---- range of every layer's screen (the warp clips to it): read back, or recomputed here after a ring extrusion -------
