@@ -189,7 +189,8 @@ def algorithmic_bytes(env):
     R, S, L_, A, nsig, cam = env.R, env._atm_tables.S, env.param.nLayer, env.nValidAct, env.nSignal, env.cam_res
     step = L_ * S * S * 4 + R * R * 4 + R * R * 4 + cam * cam * 4 + (A + nsig + A) * 4
     per = {"env_step": step, "phase": L_ * S * S * 4 + R * R * 4, "sh_spots": R * R * 4 + cam * cam * 4,
-           "sh_centroid": cam * cam * 4 + nsig * 4, "sh_tail": cam * cam * 4 + (nsig + 2 * A) * 4}
+           "sh_centroid": cam * cam * 4 + nsig * 4, "sh_tail": cam * cam * 4 + (nsig + 2 * A) * 4,
+           "detector": 2 * cam * cam * 4}                          # the stand-alone camera: frame in, frame out
     if env.wfs_type == "pyr":
         N, nt = env._pyr_tables.nRes, env._wfs_n_theta
         # as implemented: rows pass R x N complex out, column pass reads it and writes N x N, inverse row pass reads that

@@ -286,7 +286,8 @@ int aoenv_set_option(AoEnv* env, int option, int value);
  * AoKernel.  aoenv_profile(env, 0|1) also clears the recorded events. */
 enum AoKernel {
     AOENV_K_SHIFT_GATHER = 0, AOENV_K_MT_NORMAL, AOENV_K_GEMM_RING, AOENV_K_SCATTER, AOENV_K_PHASE,
-    AOENV_K_SH_SPOTS, AOENV_K_SH_CENTROID, AOENV_K_GEMM_RECON, AOENV_K_RECON_FINISH, AOENV_K_PYRAMID, AOENV_K_SH_TAIL, AOENV_K_ENV_STEP, AOENV_K_COUNT
+    AOENV_K_SH_SPOTS, AOENV_K_SH_CENTROID, AOENV_K_GEMM_RECON, AOENV_K_RECON_FINISH, AOENV_K_PYRAMID, AOENV_K_SH_TAIL, AOENV_K_ENV_STEP,
+    AOENV_K_DETECTOR, AOENV_K_COUNT
 };
 int aoenv_profile(AoEnv* env, int enable);
 int aoenv_profile_read(AoEnv* env, double* h_ms, int32_t* h_count, void* stream);

@@ -23,7 +23,7 @@ WFS_SH, WFS_PYRAMID = 0, 1
 (OPT_FAST_WFS, OPT_MFMA_GEMM, OPT_FAST_TRIG, OPT_STORE_ATM_OPD, OPT_FUSED_TAIL, OPT_FUSED_STEP, OPT_DEFER_RING, OPT_COEFS_IMAGE,
  OPT_FACTORED_RECON, OPT_RING_LOOKAHEAD) = range(10)
 KERNEL_NAMES = ("ring_prepare", "mt_normal", "gemm_ring", "ring_scatter", "phase", "sh_spots", "sh_centroid",
-                "gemm_recon", "recon_finish", "pyramid", "sh_tail", "env_step")
+                "gemm_recon", "recon_finish", "pyramid", "sh_tail", "env_step", "detector")
 
 
 class AoCfg(C.Structure):

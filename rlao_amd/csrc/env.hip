@@ -479,6 +479,7 @@ template <typename T>
 int apply_detector(AoEnv* env, bool sh, hipStream_t st) {
     if (!env->det.active) return 0;
     env->det.frame_counter += 1;
+    AO_PROF(env, DETECTOR, st);
     return launch_detector<T>(env->as<T>(env->frame), env->as<T>(env->wfs_max), sh ? env->valid2d : nullptr, env->E,
                               env->c.cam_res, env->nSub, env->det, st);
 }
