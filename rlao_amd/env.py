@@ -366,12 +366,15 @@ class BatchedAOEnv:
     ``output='torch'`` (default): device tensors with a leading N dimension.
     ``output='numpy'`` with ``n_envs == 1``: the reference's exact return types, so the stock
     ``TorchWrapper`` / trainers run unchanged.
+    ``return_frame``: True (default) -- ``step`` returns a new tensor with the WFS frames (one device copy per step, as the
+    reference hands out a new array); "view" -- a tensor aliasing the library's frame buffer (no copy, overwritten by the next
+    measurement); False -- None (the PO4AO trainer never looks at the frame, MAIN/PO4AO/mbrl.py:64-89).
     """
 
     metadata = {"render.modes": ["rgb_array"]}
 
     def __init__(self, n_envs: int = 1, device=None, dtype: str = "f32", output: str = "torch",
-                 return_frame: bool = True, env_seed_stride: int = 1, env_index_offset: int = 0):
+                 return_frame=True, env_seed_stride: int = 1, env_index_offset: int = 0):
         if dtype not in _NP_DT:
             raise ValueError("dtype must be 'f32' or 'f64'")
         if output not in ("torch", "numpy"):
@@ -764,11 +767,14 @@ class BatchedAOEnv:
         obs = torch.empty((N, A_, A_), device=self.device, dtype=self.tdtype)
         reward = torch.empty((N,), device=self.device, dtype=self.tdtype)
         strehl = torch.empty((N,), device=self.device, dtype=self.tdtype)
-        fr = torch.empty((N, self.cam_res, self.cam_res), device=self.device, dtype=self.tdtype) if self.return_frame else None
+        view = self.return_frame == "view"
+        fr = torch.empty((N, self.cam_res, self.cam_res), device=self.device, dtype=self.tdtype) if (self.return_frame and not view) else None
         L.check(self._shard.lib.aoenv_step(
             self._shard.h, int(i), C.c_void_p(a.data_ptr()), C.c_void_p(obs.data_ptr()),
             C.c_void_p(fr.data_ptr()) if fr is not None else None, C.c_void_p(reward.data_ptr()),
             C.c_void_p(strehl.data_ptr()), C.c_void_p(self._stream())))
+        if view:
+            fr = self._frame_alias()
         self._obs, self._reward, self._strehl, self._frame = obs, reward, strehl, fr
         self.SR.append(strehl)
         if self.output == "numpy":
@@ -777,6 +783,21 @@ class BatchedAOEnv:
         if self._done is None:
             self._done = torch.zeros(N, dtype=torch.bool, device=self.device)      # never terminal (OOPAOEnv.py:531): one shared tensor
         return obs, fr, reward, strehl, self._done, {"strehl": strehl}
+
+    def _frame_alias(self):
+        """wfs.cam.frame of every env as a tensor that ALIASES the library's buffer (no copy: 14.7 MB per step at 256 envs of the
+        8 m geometry); the next measurement overwrites it.  ``return_frame="view"``."""
+        if getattr(self, "_frame_view", None) is None:
+            ptr, nbytes = C.c_void_p(), C.c_size_t()
+            L.check(self._shard.lib.aoenv_buffer(self._shard.h, L.B_FRAME, C.byref(ptr), C.byref(nbytes)))
+
+            class _Iface:
+                pass
+            o = _Iface()
+            o.__cuda_array_interface__ = {"shape": (self.n_envs, self.cam_res, self.cam_res), "typestr": "<f4" if self.dtype == "f32" else "<f8",
+                                          "data": (int(ptr.value), False), "version": 2, "strides": None}
+            self._frame_view = _torch().as_tensor(o, device=self.device)
+        return self._frame_view
 
     def run_integrator(self, i0: int, n_steps: int, gain=None):
         """On-device closed loop of MAIN/integrator_oopao_razor.py:66-91: ``action = gainCL * obs`` fused into

@@ -474,3 +474,32 @@ def test_long_closed_loop_tracks_the_oracle():
     np.testing.assert_allclose(env.residual[:300, 0], ref.residual[:300], atol=5e-3)
     np.testing.assert_allclose(env.total[:300, 0], ref.total[:300], atol=5e-3)
     env.close()
+
+
+def test_frame_view_is_the_copied_frame_without_the_copy():
+    """return_frame="view": step() hands out a tensor aliasing the library's frame buffer (no device copy per step); same values as
+    the copied frame, overwritten by the next step; return_frame=False hands out None."""
+    import torch
+    from rlao_amd.env import BatchedAOEnv
+    outs = {}
+    for mode in (True, "view", False):
+        env = BatchedAOEnv(n_envs=3, device=0, dtype="f32", return_frame=mode)
+        env.set_params(SMALL, camera="papyrus", wfs_type="shackhartmann")
+        env.generate_new_phase_screen(2)
+        env.dm.coefs = 0
+        env.dm_prev = 0
+        env.measure()
+        obs = env.reset_soft()
+        frames = []
+        for i in range(3):
+            obs, fr, _, _, _, _ = env.step(i, 0.5 * obs)
+            frames.append(fr)
+        torch.cuda.synchronize()
+        outs[mode] = (obs.clone(), frames, None if frames[-1] is None else frames[-1].clone())
+        env.close()
+    assert outs[False][1] == [None, None, None]
+    assert torch.equal(outs[True][0], outs["view"][0]) and torch.equal(outs[True][0], outs[False][0])
+    assert torch.equal(outs[True][2], outs["view"][2])                          # the last frame: the same
+    assert outs["view"][1][0].data_ptr() == outs["view"][1][2].data_ptr()       # one buffer, overwritten ...
+    assert outs[True][1][0].data_ptr() != outs[True][1][2].data_ptr()           # ... against a new tensor per step
+    assert not torch.equal(outs[True][1][0], outs[True][1][2])
