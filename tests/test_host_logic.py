@@ -187,3 +187,47 @@ def test_bench_cpu_baseline_runs_the_oracle_with_the_camera():
     import bench
     out = bench.cpu_baseline("papyrus", 0.3, all_cores=False)
     assert out["cores"] == 1 and out["kind"] == "port" and out["value"] > 0 and "camera: papyrus" in out["sample"]
+
+
+def test_atmosphere_clock_source_matches_the_oracle(tmp_path):
+    """rlao_amd/csrc/common.hpp::clock_subpixel / taps_from_buff -- ONE source for the host clock (one wind per shard) and for the
+    device clocks of per-env winds (k_ring_prepare_env) -- compiled for the host and stepped next to the oracle's updateLayer
+    arithmetic (OOPAO/Atmosphere.py:392-407): accumulators and pixel crossings bit for bit, the warp's tap offsets exactly, its four
+    Catmull-Rom weights against the oracle's cubic evaluated on unit vectors."""
+    import shutil
+    import subprocess
+    from oracle import ao_oracle as O
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "clock_driver"
+    subprocess.run([hipcc, "-O1", "-std=c++17", "-x", "hip", "--cuda-host-only", f"-I{repo}/include", f"-I{repo}/rlao_amd/csrc",
+                    os.path.join(repo, "tests", "native", "clock_driver.cpp"), "-o", str(exe)], check=True, capture_output=True)
+    cases = [(0.1537, 0.047), (-0.9, 0.0), (0.0, -0.31), (0.73, -0.73), (1e-3, 0.999), (-0.25, -0.5)]
+    n = 300
+    out = subprocess.run([str(exe)], input="".join(f"{rx!r} {ry!r} {n}\n" for rx, ry in cases), text=True, capture_output=True, check=True)
+    rows = np.array([[float(v) for v in line.split()] for line in out.stdout.strip().splitlines()]).reshape(len(cases), n, 14)
+    unit = np.eye(4)
+    for (rx, ry), got in zip(cases, rows):
+        ratio = np.array([rx, ry])
+        buff = np.zeros(2)
+        crossings = 0
+        for i in range(n):
+            buff = buff + (np.abs(ratio) % 1) * np.sign(ratio)                 # ao_oracle.OracleLayer.update
+            step = np.zeros(2)
+            if np.abs(buff[0]) >= 1 or np.abs(buff[1]) >= 1:
+                step = 1 * np.sign(buff)
+                step[np.where(np.abs(buff) < 1)] = 0
+            buff = (np.abs(buff) % 1) * np.sign(buff)
+            crossings += int(step.any())
+            assert got[i, 0] == step[0] and got[i, 1] == step[1], (rx, ry, i)
+            assert got[i, 2] == buff[0] and got[i, 3] == buff[1], (rx, ry, i)   # bit for bit
+            # warp_translate(map, tx = buff_x, ty = buff_y): sampling point r - ty -> offset floor(-ty), fraction, cubic weights
+            for d, (b, col) in enumerate(((buff[1], 6), (buff[0], 10))):
+                f = -b
+                k = np.floor(f)
+                assert got[i, 4 + d] == k
+                w = np.array([O._cubic(f - k, *unit[j]) for j in range(4)])
+                np.testing.assert_allclose(got[i, col:col + 4], w, rtol=0, atol=2e-15)
+        assert crossings >= int(n * np.abs(ratio).max()) - 1                      # at least the faster axis' pixel count
