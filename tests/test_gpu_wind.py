@@ -165,3 +165,25 @@ def test_atm_update_alone_moves_the_atmosphere_like_a_step(dtype):
     np.testing.assert_allclose(fa, fb, atol=(0 if dtype == "f64" else 2e-5) * fb.max())   # (float32: batched vs fused kernels)
     a.close()
     b.close()
+
+
+def test_per_env_winds_under_the_pyramid():
+    """The Pyramid runs the batched kernels in float32 (no fused step): 4 envs, 4 winds, each bit-identical to a shard with that wind."""
+    import torch
+    from rlao_amd.env import BatchedAOEnv
+    geo = dict(SMALL, modulation=0.0)
+    sp, di = SPEEDS[[0, 2, 3, 5]], DIRS[[0, 2, 3, 5]]
+    env = BatchedAOEnv(n_envs=4, device=0, dtype="f32", env_seed_stride=0)
+    env.set_params(geo, camera="ideal", wfs_type="pyramid")
+    got = _episode(env, 16, 5, winds=(sp, di))
+    env.close()
+    for e in range(4):
+        ref = BatchedAOEnv(n_envs=1, device=0, dtype="f32", env_seed_stride=0)
+        ref.set_params(geo, camera="ideal", wfs_type="pyramid")
+        ref.atm.windSpeed = list(sp[e])
+        ref.atm.windDirection = list(di[e])
+        want = _episode(ref, 16, 5)
+        ref.close()
+        for (o, f, r, s_), (o0, f0, r0, s0) in zip(got, want):
+            assert torch.equal(o[e], o0[0]) and torch.equal(f[e], f0[0]) and torch.equal(r[e], r0[0]) and torch.equal(s_[e], s0[0]), e
+    assert not torch.equal(got[-1][0][0], got[-1][0][2])
