@@ -280,6 +280,12 @@ enum AoOption {
 };
 int aoenv_set_option(AoEnv* env, int option, int value);
 
+/* Which path aoenv_step would take with the tables, options and camera as they are now: 1 = the whole step as one kernel
+ * (float32 Shack-Hartmann, 6 pixels per lenslet, <= 336 valid lenslets, R <= 128, <= 32 actuators across, <= 52 modes, reconstructor
+ * factors uploaded), 0 = the batched kernels (3-5 launches per step, roughly half the speed at small geometries).  A caller
+ * outside the envelope is told instead of finding out from a profile. */
+int aoenv_fused_step_active(AoEnv* env);
+
 /* Per-kernel timing (bench.py roofline leg).  While enabled, every kernel launch of aoenv_step /
  * aoenv_measure is bracketed by a hipEvent pair recorded on the launch stream; aoenv_profile_read
  * synchronises the stream and returns the summed elapsed milliseconds and the launch count of each

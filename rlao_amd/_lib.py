@@ -54,6 +54,7 @@ EXPORTS = {
     "aoenv_set_atm_opd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "aoenv_set_coefs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "aoenv_measure": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "aoenv_fused_step_active": (C.c_int, [C.c_void_p]),
     "aoenv_atm_update": (C.c_int, [C.c_void_p, C.c_void_p]),
     "aoenv_reset_soft": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "aoenv_step": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

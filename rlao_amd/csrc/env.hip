@@ -1772,6 +1772,11 @@ int aoenv_set_buff(AoEnv* env, const double* h_buff) {
     return 0;
 }
 
+int aoenv_fused_step_active(AoEnv* env) {
+    if (!env) return 0;
+    return env->c.dtype == AOENV_F32 && fused_step_ok<float>(env) ? 1 : 0;
+}
+
 int aoenv_set_option(AoEnv* env, int option, int value) {
     AO_CHECK_ENV(env);
     switch (option) {

@@ -784,6 +784,12 @@ class BatchedAOEnv:
             self._done = torch.zeros(N, dtype=torch.bool, device=self.device)      # never terminal (OOPAOEnv.py:531): one shared tensor
         return obs, fr, reward, strehl, self._done, {"strehl": strehl}
 
+    @property
+    def fused_step(self) -> bool:
+        """True when ``step`` runs as ONE kernel per step (float32 Shack-Hartmann inside the fused kernel's envelope, see
+        aoenv_fused_step_active in include/aoenv.h); False: the batched kernels (every geometry, float64, the Pyramid)."""
+        return bool(self._shard.lib.aoenv_fused_step_active(self._shard.h))
+
     def _frame_alias(self):
         """wfs.cam.frame of every env as a tensor that ALIASES the library's buffer (no copy: 14.7 MB per step at 256 envs of the
         8 m geometry); the next measurement overwrites it.  ``return_frame="view"``."""

@@ -503,3 +503,19 @@ def test_frame_view_is_the_copied_frame_without_the_copy():
     assert outs["view"][1][0].data_ptr() == outs["view"][1][2].data_ptr()       # one buffer, overwritten ...
     assert outs[True][1][0].data_ptr() != outs[True][1][2].data_ptr()           # ... against a new tensor per step
     assert not torch.equal(outs[True][1][0], outs[True][1][2])
+
+
+def test_fused_step_query_tells_which_path_runs():
+    """env.fused_step (aoenv_fused_step_active): the one-kernel step inside its envelope, the batched kernels outside it."""
+    from rlao_amd import _lib as L
+    from rlao_amd.env import BatchedAOEnv
+    for dtype, wfs, geo, want in (("f32", "shackhartmann", SMALL, True), ("f64", "shackhartmann", SMALL, False),
+                                  ("f32", "pyramid", dict(SMALL, modulation=0.0), False),
+                                  ("f32", "shackhartmann", dict(SMALL, nModes=60), False)):       # > 52 modes: outside the envelope
+        env = BatchedAOEnv(n_envs=2, device=0, dtype=dtype)
+        env.set_params(geo, camera="ideal", wfs_type=wfs)
+        assert env.fused_step is want, (dtype, wfs)
+        if want:
+            L.check(env._shard.lib.aoenv_set_option(env._shard.h, L.OPT_FUSED_STEP, 0))
+            assert env.fused_step is False
+        env.close()
