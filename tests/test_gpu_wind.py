@@ -187,3 +187,47 @@ def test_per_env_winds_under_the_pyramid():
         for (o, f, r, s_), (o0, f0, r0, s0) in zip(got, want):
             assert torch.equal(o[e], o0[0]) and torch.equal(f[e], f0[0]) and torch.equal(r[e], r0[0]) and torch.equal(s_[e], s0[0]), e
     assert not torch.equal(got[-1][0][0], got[-1][0][2])
+
+
+def test_ring_pipeline_survives_wind_changes_and_other_consumers():
+    """The operand of a layer's next crossing is prepared ahead (ring pipeline, AOENV_OPT_RING_LOOKAHEAD); whatever invalidates it must
+    fall back to preparing in place: wind speed / direction changed in mid-episode (the next crossing may go the other way), a
+    stand-alone measurement or atm.update() between steps (another consumer of the deferred ring), a checkpoint restored.  Pipeline
+    on == pipeline off, bit for bit, through all of it."""
+    import torch
+    from rlao_amd import _lib as L
+    outs = []
+    for pipeline in (1, 0):
+        env = _make(3, "f32")
+        env.env_seed_stride = 1
+        L.check(env._shard.lib.aoenv_set_option(env._shard.h, L.OPT_RING_LOOKAHEAD, pipeline))
+        env.atm.windSpeed = [25.0]
+        env.generate_new_phase_screen(8)
+        env.dm.coefs = 0
+        env.dm_prev = 0
+        env.measure()
+        obs = env.reset_soft()
+        log = []
+        snap = None
+        for i in range(40):
+            if i == 7:
+                env.atm.windDirection = [250.0]                      # the prepared Z is for the old direction
+            if i == 13:
+                env.atm.windSpeed = [9.0]
+            if i == 17:
+                env.measure()                                        # tel*dm*wfs between two steps
+            if i == 21:
+                env.atm.update()                                     # the atmosphere alone moves a frame
+            if i == 26:
+                snap = env.get_state()
+            if i == 31:
+                env.set_state(snap)                                  # back to step 26's state (the loop goes on from there)
+                obs = torch.as_tensor(snap["obs"], device=env.device)
+            obs, frame, rew, sr, _, _ = env.step(i, 0.5 * obs)
+            log.append((obs.clone(), frame.clone(), rew.clone(), sr.clone()))
+        torch.cuda.synchronize()
+        outs.append(log)
+        env.close()
+    for i, (x, y) in enumerate(zip(*outs)):
+        assert all(torch.equal(p, q) for p, q in zip(x, y)), i
+    assert not torch.equal(outs[0][6][0], outs[0][30][0])
