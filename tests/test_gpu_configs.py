@@ -180,3 +180,29 @@ def test_c4_elt_measurement_matches_reference_and_ring_matches_oracle(golden_dir
                 assert abs(buff[0, 0]) < 1 and env._shard.download(L.B_XI, (n_envs, env._atm_tables.n_inner + 1940)).any()
         finally:
             env.close()
+
+
+def test_c2_geometry_1000_envs_ragged_shard():
+    """A shard that is neither a multiple of the ring GEMM's 64-env tiles nor of the 256 CUs (1000 envs of the configs[1] geometry,
+    photon noise on): the step kernel runs in four rounds of workgroups, the last GEMM tile is ragged; batch invariance, bitwise
+    reruns, distinct seeds -- and env 999 of the big shard == env 0 of a 1-env shard given its seed and its noise-stream index."""
+    import torch
+    from rlao_amd.env import BatchedAOEnv
+    geo = dict(C5, windSpeed=[10.0], windDirection=[72.0], fractionalR0=[1.0], altitude=[0.0])
+    env = BatchedAOEnv(n_envs=1000, device=0, dtype="f32", env_seed_stride=0)
+    try:
+        env.set_params(geo, camera="papyrus", wfs_type="shackhartmann")
+        assert env.fused_step
+        env.env_seed_stride = 1
+        big = _episode(env, 9, 17)
+    finally:
+        env.close()
+    one = BatchedAOEnv(n_envs=1, device=0, dtype="f32", env_index_offset=999)
+    try:
+        one.set_params(geo, camera="papyrus", wfs_type="shackhartmann")
+        small = _episode(one, 9, 17)                               # env_seeds: seed + (offset + e) * stride = 17 + 999
+    finally:
+        one.close()
+    for x, y in zip(big, small):
+        assert all(torch.equal(p[999], q[0]) for p, q in zip(x, y))
+    assert float(big[-1][3].std()) > 0
