@@ -302,6 +302,16 @@ int aoenv_profile_read(AoEnv* env, double* h_ms, int32_t* h_count, void* stream)
  * legacy polar generator into h_out (float64), to pin the stream against NumPy. */
 int aoenv_test_normal(int device, uint32_t seed, int n, int n_calls, double* h_out);
 
+/* Test hooks of the camera's photon-noise sampler (rlao_amd/csrc/poisson_alias.hpp; replaces the NumPy draw of
+ * OOPAO/Detector.py:204-206, whose law -- not whose stream -- is what can be matched: the reference seeds it from the wall clock).
+ * aoenv_test_poisson_table: the alias tables as the kernels read them (host only, no GPU needed): h_words = size in 32-bit
+ *   words; h_out (cap_words >= that) receives header {fine rows, coarse rows, words, 0}, row descriptors {first entry, kmin << 16 |
+ *   cells} and entries {23-bit threshold << 9 | alias}.  A CPU test rebuilds every row's outcome probabilities from them.
+ * aoenv_test_poisson: h_out[i] = one draw of Poisson(h_lambda[i]) by the cameras' code path, stream (seed, frame); lmax > 0 lowers
+ *   the photon count from which PTRS takes over (a multiple of 32, at least 32), 0 = the table's own end (1024). */
+int aoenv_test_poisson_table(uint32_t* h_out, size_t cap_words, size_t* h_words);
+int aoenv_test_poisson(int device, const float* h_lambda, int n, uint64_t seed, uint32_t frame, float lmax, float* h_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -296,13 +296,16 @@ class OracleAtmosphere:
     wavelength = 500e-9
 
     def __init__(self, tel_resolution, tel_D, dt, pupil, r0, L0, windSpeed, fractionalR0,
-                 windDirection, altitude, fov_rad=0.0):
+                 windDirection, altitude, fov_rad=0.0, geom_AB=None):
+        """geom_AB = (LayerGeometry, A, B): operators computed by the caller (fov = 0; the ELT-size ones take minutes)."""
         self.R, self.D, self.dt, self.pupil = tel_resolution, tel_D, dt, pupil
         self.r0, self.L0 = r0, L0
         self.fractionalR0 = list(fractionalR0)
         self.nLayer = len(self.fractionalR0)
         self.layers = []
         geom = None
+        if geom_AB is not None and fov_rad == 0:
+            geom, A, B = geom_AB
         for i in range(self.nLayer):
             if geom is None or fov_rad != 0:
                 geom = LayerGeometry(tel_resolution, tel_D, L0, altitude=altitude[i], fov_rad=fov_rad)
@@ -761,17 +764,22 @@ class OracleEnv:
                  r0=0.13, L0=30.0, windSpeed=(10.0,), windDirection=(72.0,), fractionalR0=(1.0,),
                  altitude=(0.0,), mech_coupling=0.35, m2c=None, n_modes=50, light_ratio=None,
                  threshold_cog=0.01, nLoop=10000, leak=0.99, gainCL=0.5, n_meas=6, wfs_type="sh", modulation=0.0,
-                 psf_centering=True, second_dm_nsub=None, modal_cm=None):
+                 psf_centering=True, second_dm_nsub=None, modal_cm=None, dm_dense=True, geom_AB=None):
         self.R, self.D, self.dt = resolution, diameter, dt
         self.leak, self.gainCL = leak, gainCL
         self.pupil = make_pupil(resolution)
         self.wavelength, self.nPhoton = source_photometry(band, magnitude)
         self.flux_map = self.pupil.astype(float) * self.nPhoton * dt * (diameter / resolution) ** 2
         self.atm = OracleAtmosphere(resolution, diameter, dt, self.pupil, r0, L0, windSpeed, fractionalR0,
-                                    windDirection, altitude)
+                                    windDirection, altitude, geom_AB=geom_AB)
         self.nActuator = n_subap + 1
-        dm = dm_geometry(resolution, diameter, n_subap, mech_coupling, pitch=diameter / self.nActuator)
+        # dm_dense = False (ELT size: dm.modes would be 9.6 GB): the DM surface through the separable factors,
+        # OPD = gy C gx^T with C the command image -- equal to modes @ coefs to rounding (tests/test_oracle_golden.py)
+        dm = dm_geometry(resolution, diameter, n_subap, mech_coupling, pitch=diameter / self.nActuator, dense=dm_dense)
         self.dm_modes = dm["modes"]
+        self.dm_valid_flat = np.flatnonzero(dm["validAct"])
+        if not dm_dense and (second_dm_nsub is not None or m2c is None):
+            raise ValueError("dm_dense=False: one DM, and the mode-to-command matrix handed over")
         self.gx, self.gy = dm["gx"], dm["gy"]
         self.dm_mask = dm["validAct"].reshape(self.nActuator, self.nActuator)
         self.xvalid, self.yvalid = np.nonzero(self.dm_mask)
@@ -826,6 +834,11 @@ class OracleEnv:
 
     # -- helpers --------------------------------------------------------------------
     def dm_opd(self, coefs):
+        if self.dm_modes is None:                               # separable form of the same product (dm_dense=False)
+            n1 = self.nActuator
+            C = np.zeros(n1 * n1)
+            C[self.dm_valid_flat] = coefs
+            return self.gy @ C.reshape(n1, n1) @ self.gx.T
         return (self.dm_modes @ coefs).reshape(self.R, self.R)  # DeformableMirror.py:556
 
     def vec_to_img(self, v):

@@ -343,10 +343,28 @@ def make_c4_sh(ref):
         tel.OPD = opd_in * tel.pupil
         tel * dm * wfs
     frame = np.asarray(wfs.cam.frame, dtype=np.float64)
-    out = dict(cfg_R=R, cfg_nsub=ns, cfg_D=D, coefs=coefs, validAct=np.asarray(dm.validAct, bool),
+    signal = np.asarray(wfs.signal, dtype=np.float64).copy()
+    opd_res = np.asarray(tel.OPD, dtype=np.float64).copy()
+    # Three measurement groups of the zonal interaction matrix (OOPAOEnv.py:278-288: M2C = identity, stroke = lambda / 16,
+    # nMeasurements = 6, single pass): the first, a middle and the last group of consecutive actuators, each measured by the
+    # reference's InteractionMatrix exactly as a cycle of the full 5209-column call measures it (a cycle's pokes share the
+    # centroid threshold, ShackHartmann.py:605-672; the last cycle holds the 5209 % 6 = 1 last actuator).
+    nv = int(dm.nValidAct)
+    imat_idx, imat_cols = [], []
+    for gidx in (0, (nv // 6) // 2, nv // 6):
+        lo, hi = 6 * gidx, min(6 * gidx + 6, nv)
+        m2c = np.zeros((nv, hi - lo))
+        m2c[np.arange(lo, hi), np.arange(hi - lo)] = 1.0
+        with RL.quiet():
+            cal = ref.InteractionMatrix(ngs=ngs, atm=None, tel=tel, dm=dm, wfs=wfs, M2C=m2c, stroke=ngs.wavelength / 16,
+                                        nMeasurements=6, noise="off", invert=False, display=False, single_pass=True)
+        imat_idx += list(range(lo, hi))
+        imat_cols.append(np.asarray(cal.D, dtype=np.float64).reshape(wfs.nSignal, hi - lo))
+        print(f"c4_sh: interaction-matrix group {gidx} (actuators {lo}..{hi - 1}) measured", flush=True)
+    out = dict(cfg_R=R, cfg_nsub=ns, cfg_D=D, coefs=coefs, imat_idx=np.asarray(imat_idx, dtype=np.int64), imat_cols=np.hstack(imat_cols), validAct=np.asarray(dm.validAct, bool),
                valid_subap=np.asarray(wfs.valid_subapertures, bool), reference_slopes_maps=wfs.reference_slopes_maps,
-               slopes_units=wfs.slopes_units, signal=np.asarray(wfs.signal, dtype=np.float64),
-               opd_res_rows=np.asarray(tel.OPD, dtype=np.float64)[::16], frame_rows=frame[::8],
+               slopes_units=wfs.slopes_units, signal=signal,
+               opd_res_rows=opd_res[::16], frame_rows=frame[::8],
                frame_sum=frame.sum(), frame_max=frame.max(), frame_sq=np.sqrt((frame ** 2).sum()),
                frame_colsum=frame.sum(axis=0), frame_rowsum=frame.sum(axis=1))
     path = os.path.join(GOLD, "c4_sh.npz")

@@ -76,6 +76,8 @@ EXPORTS = {
     "aoenv_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "aoenv_profile_read": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "aoenv_test_normal": (C.c_int, [C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_void_p]),
+    "aoenv_test_poisson_table": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "aoenv_test_poisson": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_uint64, C.c_uint32, C.c_float, C.c_void_p]),
 }
 
 

@@ -257,6 +257,10 @@ struct DetectorCfg {           // by value into kernels
     uint32_t env_offset;       // global index of env 0 of this shard
 };
 
+}  // namespace ao
+#include "poisson_alias.hpp"
+namespace ao {
+
 // fused per-env step kernel (step_kernel.hip): float32, 6 px per lenslet, separable DM, factored reconstructor
 struct StepArgs {
     KArgs<float> k;
@@ -272,6 +276,7 @@ struct StepArgs {
     const float* gxa;            // [128][4][8] gx[x][q + 4 s] at [x][q][s], zero padded: MFMA operands as two 16-byte loads
     const float* gya;            // [128][4][8] gy[y][q + 4 s]
     DetectorCfg det;             // WFS camera (active = 0: ideal)
+    PoissonAlias pa;             // its photon-noise tables (poisson_alias.hpp)
     // ring extrusion whose scatter was deferred to this kernel (add_row part 3, OOPAO/Atmosphere.py:309-310):
     const float* ring_x[kMaxLayer];   // [splits][E][n_outer] split-K slabs of X = A Z + B xi of the layer, null = nothing pending
     int ring_splits[kMaxLayer];

@@ -10,24 +10,25 @@
 // distribution.  Here the random numbers come from counter-based Philox4x32-7 streams keyed by `seed` and indexed by (pixel
 // group, global env index, frame counter, purpose): reproducible, independent of the batch layout and of the kernel variant.
 //
-// Stream layout (the fused step kernel and k_detector draw the same numbers):
+// Stream layout (the fused step kernel, k_detector_sh6 and k_detector draw the same numbers):
 //   * the frame is cut into QUADS of 4 pixels; one Philox call per (quad, purpose) serves its 4 pixels, slot s gets word s:
-//       purpose 0  photon noise: the uniform of a faint pixel (lambda < kPtrsFrom: inversion by sequential search, exact, ONE
-//                  uniform) or the proposal uniform U of a bright pixel's first PTRS round
-//       purpose 3  photon noise: the acceptance uniform V of a bright pixel's first PTRS round (Hoermann's transformed rejection,
-//                  exact; the algorithm NumPy's legacy generator uses from lambda = 10); its squeeze accepts ~86 % there and then
-//       purpose 1  dark shot noise: one uniform, inversion
+//       purpose 0  photon noise: the word of the fine alias draw (poisson_alias.hpp)
+//       purpose 3  photon noise: the uniform of the remainder's inversion
+//       purpose 4  photon noise: the word of the coarse alias draw -- drawn only where a wave holds a pixel of 32 photons or more
+//       purpose 1  dark shot noise: one uniform, inversion (purpose 5: the second uniform of PTRS for dark_e >= 10)
 //       purpose 2  read-out noise: slots (0, 1) and (2, 3) share a Box-Muller pair (cos / sin branch)
-//   * a bright pixel whose first round is rejected (~8 %) goes on with a stream of its own, (pixel, env, frame, 16 + j), two
-//     uniforms per round.
+//   * a pixel at or above the end of the alias table (1024 photons) is drawn by PTRS from the words of purposes 0 and 4; a round-0
+//     rejection (~8 %) goes on with a stream of its own, (pixel, env, frame, 16 + j), two uniforms per round.
 //   Quads: Shack-Hartmann frames with 6-pixel lenslets use the lane -> pixel map of the fused step kernel (a lane owns rows
 //   0..5 of the lenslet columns q and q + 3): rows 0..3 of a column are one quad, rows 4..5 of the columns c and c + 3 another.
 //   Any other frame: 4 consecutive pixels of a row.  A quad is named by the frame index of its slot-0 pixel.
 // Cost (why it is laid out like this): a Philox call is ~100 issue slots (its 32 x 32 multiplies are quarter rate); one call per
 // pixel and one data-dependent sampler per pixel (a wave runs both the faint and the bright branch, for as many rounds as
-// its slowest lane) made the camera cost more than the physics (round 1: step kernel 40 -> 92 us with photon noise).
+// its slowest lane) made the camera cost more than the physics (round 1: step kernel 40 -> 92 us with photon noise; round 2, quads
+// + lock-step inversion + PTRS with LDS queues: 61 us; round 3: the fixed-cost alias sampler of poisson_alias.hpp).
 #pragma once
 #include "common.hpp"
+#include "poisson_alias.hpp"
 
 namespace ao {
 
@@ -52,7 +53,8 @@ __device__ inline void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_
     out[0] = p.c[0]; out[1] = p.c[1]; out[2] = p.c[2]; out[3] = p.c[3];
 }
 
-__device__ inline float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }   // (0, 1)
+// strictly inside (0, 1): 23 bits + 1/2 ((x >> 8) + 0.5 rounds to 2^24 for the top word: a uniform of exactly 1)
+__device__ inline float u01(uint32_t x) { return ((float)(x >> 9) + 0.5f) * (1.0f / 8388608.0f); }
 
 // (4-vectors indexed by a loop counter are ext_vector registers: the compiler indexes those with v_movrel, while a float[4] --
 //  even behind a select chain -- is turned into an indexed array in scratch memory)
@@ -60,7 +62,7 @@ typedef float f32x4d __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4d __attribute__((ext_vector_type(4)));
 
 constexpr float kPtrsFrom = 10.f;                              // PTRS is valid from lambda = 10 (NumPy switches there too)
-enum { kDrawPhoton = 0, kDrawDark = 1, kDrawReadout = 2, kDrawPhoton2 = 3, kDrawPixelStream = 16 };
+enum { kDrawPhoton = 0, kDrawDark = 1, kDrawReadout = 2, kDrawPhoton2 = 3, kDrawPhoton3 = 4, kDrawDark2 = 5, kDrawPixelStream = 16 };
 
 __device__ inline void quad_bits(uint32_t quad, uint32_t env, const DetectorCfg& d, uint32_t purpose, uint32_t (&o)[4]) {
     philox4x32(quad, env + d.env_offset, d.frame_counter, purpose, d.seed_lo, d.seed_hi, o);
@@ -70,36 +72,17 @@ __device__ inline void quad_bits(uint32_t quad, uint32_t env, const DetectorCfg&
 // v_readlane instead of a quarter-rate v_rcp per lane and step)
 __device__ inline float recip_table_lane() { return 1.0f / (float)((threadIdx.x & 63) + 1); }
 
-// Poisson(lam), lam < kPtrsFrom (any lam < ~20 is sampled correctly): inversion by sequential search with ONE uniform,
-// X = #{k >= 0 : u > F(k)}.  The lanes of a wave walk k together, 4 steps per vote; a lane that has found its X keeps
-// counting zeros.  64 steps cover the tail far below float32 resolution.  `active` lanes only (others: lam = 0 -> 0).
+// Poisson(lam) for ONE lam shared by the wave (the dark current), lam < kPtrsFrom: inversion by sequential search with ONE uniform,
+// X = #{k >= 0 : u > F(k)}.  The lanes walk k together, 4 steps per vote; a lane that has found its X keeps counting zeros; the
+// search ends when the terms have underflowed (cdf no longer grows), at 64 steps at the latest.
 __device__ inline float poisson_inversion(float lam, float u, float rtab) {
     float p = __expf(-lam), cdf = p, k = 0.f;
     for (int k0 = 0; k0 < 64; k0 += 4) {
-        if (!__any(u > cdf)) break;
+        if (!__any(u > cdf) || !__any(p > 0.f)) break;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            k += u > cdf ? 1.f : 0.f;                                         // X > t = k0 + j
+            k += (u > cdf && p > 0.f) ? 1.f : 0.f;                            // X > t = k0 + j
             p *= lam * __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rtab), k0 + j));   // P(t + 1) = P(t) lam / (t + 1)
-            cdf += p;
-        }
-    }
-    return k;
-}
-
-// The same for TWO pixels of a lane at once, as packed float32 pairs (v_pk_mul_f32 / v_pk_add_f32): the recurrence of the
-// probability and the running sum cost one instruction per pair instead of one per pixel.
-typedef float f32x2d __attribute__((ext_vector_type(2)));
-__device__ inline f32x2d poisson_inversion2(f32x2d lam, f32x2d u, float rtab) {
-    f32x2d p = {__expf(-lam.x), __expf(-lam.y)}, cdf = p, k = {0.f, 0.f};
-    for (int k0 = 0; k0 < 64; k0 += 4) {
-        if (!__any(u.x > cdf.x || u.y > cdf.y)) break;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            k.x += u.x > cdf.x ? 1.f : 0.f;
-            k.y += u.y > cdf.y ? 1.f : 0.f;
-            const float inv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rtab), k0 + j));
-            p *= lam * inv;
             cdf += p;
         }
     }
@@ -118,8 +101,9 @@ __device__ inline float log_factorial(float k) {
     return k < 4.f ? small : st;
 }
 
-// Poisson(lam), lam >= kPtrsFrom: Hoermann's PTRS (exact; the algorithm NumPy's legacy generator uses from lam = 10).
-// Round 0 takes its two uniforms from the pixel's words of the quad draws kDrawPhoton (U) and kDrawPhoton2 (V); a pixel that
+// Poisson(lam), lam >= kPtrsFrom: Hoermann's PTRS (exact; the algorithm NumPy's legacy generator uses from lam = 10).  Used for
+// photon counts beyond the alias table and for a dark current of 10 electrons per frame or more.
+// Round 0 takes its two uniforms from the pixel's words of two quad draws (photons: kDrawPhoton (U), kDrawPhoton3 (V)); a pixel that
 // round 0 rejects (~8 % of them) goes on with a stream of its own: call j gives the uniforms of rounds 1 + 2j, 2 + 2j.
 struct PtrsConst { float b, a, lam; };
 __device__ inline PtrsConst ptrs_const(float lam) {
@@ -214,38 +198,50 @@ __device__ inline uint32_t word_of(const uint32_t (&o)[4], int s) {
     return ov[s];
 }
 
+// The photon count of one pixel: Poisson(lam) from the alias tables (poisson_alias.hpp; `tab` = the table where this kernel keeps it,
+// LDS or global), or by PTRS at and above the table's end.  EVERY lane of a wave must call (PTRS votes across the wave).
+// wf, wr, wc: the pixel's words of the quad draws kDrawPhoton, kDrawPhoton2, kDrawPhoton3 (wc is only looked at where lam >= 32).
+__device__ inline float photon_count(float lam, uint32_t wf, uint32_t wr, uint32_t wc, uint32_t pixel, uint32_t env, const DetectorCfg& d,
+                                     float lmax, const uint32_t* __restrict__ tab) {
+    const bool over = lam >= lmax;
+    float k = poisson_alias<true>(over ? 0.f : lam, wf, wr, wc, tab);
+    if (__any(over)) {
+        const float kb = poisson_ptrs(over ? lam : kPtrsFrom, wf, wc, pixel, env, d);
+        k = over ? kb : k;
+    }
+    return k;
+}
+__device__ inline float photon_count(float lam, uint32_t wf, uint32_t wr, uint32_t wc, uint32_t pixel, uint32_t env, const DetectorCfg& d,
+                                     const PoissonAlias& pa) {
+    return photon_count(lam, wf, wr, wc, pixel, env, d, pa.lmax, pa.tab);
+}
+
 // One quad of the camera, photons in -> counts out (used where the caller has no cheaper arrangement: k_detector, the unlit
 // lenslets of the fused step kernel).  pix[s]: frame index of the quad's slot-s pixel (the per-pixel stream of a bright pixel).
 // PHOTON = false: the quad is known to hold no light (unlit lenslets): only dark current / read-out / ADC.
 template <bool PHOTON = true>
-__device__ inline void detector_quad(f32x4d& v, const uint32_t (&pix)[4], uint32_t quad, uint32_t env, const DetectorCfg& d, float rtab) {
+__device__ inline void detector_quad(f32x4d& v, const uint32_t (&pix)[4], uint32_t quad, uint32_t env, const DetectorCfg& d, float rtab,
+                                     const PoissonAlias& pa) {
     const u32x4d pv = {pix[0], pix[1], pix[2], pix[3]};
     if (PHOTON && d.photon_noise) {
-        uint32_t o[4], o2[4];
+        uint32_t o[4], o2[4], o3[4] = {0u, 0u, 0u, 0u};
         quad_bits(quad, env, d, kDrawPhoton, o);
         quad_bits(quad, env, d, kDrawPhoton2, o2);
-#pragma unroll 1
-        for (int s = 0; s < 4; ++s) {
-            const float lam = v[s];
-            const bool faint = !(lam >= kPtrsFrom);
-            float k = 0.f;
-            if (__any(faint && lam > 0.f)) k = poisson_inversion(faint ? fmaxf(lam, 0.f) : 0.f, u01(word_of(o, s)), rtab);
-            if (__any(!faint)) {
-                const float kb = poisson_ptrs(faint ? kPtrsFrom : lam, word_of(o, s), word_of(o2, s), pv[s], env, d);
-                k = faint ? k : kb;
-            }
-            v[s] = k;
-        }
+        if (__any(v[0] >= palias::kCoarseStep || v[1] >= palias::kCoarseStep || v[2] >= palias::kCoarseStep || v[3] >= palias::kCoarseStep))
+            quad_bits(quad, env, d, kDrawPhoton3, o3);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) v[s] = photon_count(fmaxf(v[s], 0.f), o[s], o2[s], o3[s], pv[s], env, d, pa);
     }
     f32x4d dark = {0.f, 0.f, 0.f, 0.f}, nrm = {0.f, 0.f, 0.f, 0.f};
     if (d.dark_e > 0.f) {
-        uint32_t o[4];
+        uint32_t o[4], o2[4] = {0u, 0u, 0u, 0u};
         quad_bits(quad, env, d, kDrawDark, o);
+        if (d.dark_e >= kPtrsFrom) quad_bits(quad, env, d, kDrawDark2, o2);
 #pragma unroll 1
         for (int s = 0; s < 4; ++s) {
             const uint32_t px = pv[s];
             dark[s] = d.dark_e < kPtrsFrom ? poisson_inversion(d.dark_e, u01(word_of(o, s)), rtab)
-                                           : poisson_ptrs(d.dark_e, word_of(o, s), ~word_of(o, s) * 0x9E3779B9u, px | 0x80000000u, env, d);
+                                           : poisson_ptrs(d.dark_e, word_of(o, s), word_of(o2, s), px | 0x80000000u, env, d);
         }
     }
     if (d.readout_noise != 0.f) {
@@ -276,6 +272,6 @@ __device__ inline void sh6_quad_pixels(int j, int y0, int x0, int cam, uint32_t 
 // frame (valid2d != null) it also writes the maximum over the valid lenslets' pixels to wfs_max[E].
 template <typename T>
 int launch_detector(T* frame, T* wfs_max, const uint8_t* valid2d, int n_env, int cam, int n_subap, const DetectorCfg& d,
-                    hipStream_t st);
+                    const PoissonAlias& pa, hipStream_t st);
 
 }  // namespace ao

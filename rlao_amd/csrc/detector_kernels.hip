@@ -11,7 +11,7 @@ namespace ao {
 template <typename T>
 __global__ void __launch_bounds__(256) k_detector(T* __restrict__ frame, T* __restrict__ wfs_max,
                                                   const uint8_t* __restrict__ valid2d, int cam, int n_subap,
-                                                  const DetectorCfg d, int n_quads, int sh6) {
+                                                  const DetectorCfg d, const PoissonAlias pa, int n_quads, int sh6) {
     const int e = blockIdx.y;
     T* fr = frame + (size_t)e * cam * cam;
     const float rtab = recip_table_lane();
@@ -45,7 +45,7 @@ __global__ void __launch_bounds__(256) k_detector(T* __restrict__ frame, T* __re
         f32x4d v;
 #pragma unroll
         for (int s = 0; s < 4; ++s) v[s] = in[s] ? (float)fr[pix[s]] : 0.f;
-        detector_quad<true>(v, pix, pix[0], (uint32_t)e, d, rtab);
+        detector_quad<true>(v, pix, pix[0], (uint32_t)e, d, rtab, pa);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             if (in[s]) fr[pix[s]] = (T)v[s];
@@ -61,46 +61,49 @@ __global__ void __launch_bounds__(256) k_detector(T* __restrict__ frame, T* __re
     }
 }
 
-// Shack-Hartmann frames with 6-pixel lenslets, float32: the queue-based camera of the fused step kernel (camera_sh6.hpp), one lane
-// per (lenslet, column pair) = 12 pixels, 4 waves per workgroup.  Same streams, same samplers: the same frame as k_detector, but
-// the undecided bright pixels of a workgroup are finished densely instead of wave by wave in lock-step (ELT frames, 480^2 pixels
-// x 512 envs: 1.39 ms per frame with k_detector -- more than the phase and the spots kernels).
-__global__ void __launch_bounds__(256) k_detector_sh6(float* __restrict__ frame, float* __restrict__ wfs_max,
-                                                      const uint8_t* __restrict__ valid2d, int cam, int n_subap, const DetectorCfg d) {
-    constexpr int WAVES = 4, Q0_CAP = 1024, Q1_CAP = 512;
-    __shared__ f32x4d q0[Q0_CAP];
-    __shared__ float res[Q0_CAP];
-    __shared__ float q1[3 * Q1_CAP];
-    __shared__ int counts[WAVES + 1];
+// Shack-Hartmann frames with 6-pixel lenslets, float32: the camera block of the fused step kernel (camera_sh6.hpp), one lane per
+// (lenslet, column pair) = 12 pixels, with the alias tables of the photon draw in LDS (58 KB, copied by direct loads while the
+// first pixels are on their way; a workgroup of 8 waves serves `chunks` runs of 512 lanes so that the copy is paid once per ~25 k
+// pixels).  Same streams, same sampler as k_detector (whose table reads go through the caches): the same frame.
+// (ELT frames, 480^2 pixels x 512 envs: 1.39 ms per frame with k_detector and NumPy's samplers, 1.03 ms with the round-2 queues.)
+__global__ void __launch_bounds__(512) k_detector_sh6(float* __restrict__ frame, float* __restrict__ wfs_max,
+                                                      const uint8_t* __restrict__ valid2d, int cam, int n_subap, const DetectorCfg d,
+                                                      const PoissonAlias pa, int chunks) {
+    constexpr int WAVES = 8;
+    __shared__ __align__(16) uint32_t tab_s[palias::kMaxWords];
     const int e = blockIdx.y, tid = threadIdx.x, w = tid / kWave, lane = tid & (kWave - 1);
-    const int task = blockIdx.x * 256 + tid, n_tasks = n_subap * n_subap * 3;
-    const bool live = task < n_tasks;
-    const int k = (live ? task : 0) / 3, q3 = (live ? task : 0) - 3 * k;
-    const int li = k / n_subap, lj = k - li * n_subap;
-    const uint32_t px0 = (uint32_t)((li * 6) * cam + lj * 6 + q3);
-    float* fr = frame + (size_t)e * cam * cam + px0;
-    if (tid < WAVES + 1) counts[tid] = 0;
-    f32x16s pxv;
-#pragma unroll
-    for (int u = 0; u < 6; ++u) {
-        pxv[u] = live ? fr[(size_t)u * cam] : 0.f;
-        pxv[6 + u] = live ? fr[(size_t)u * cam + 3] : 0.f;
-    }
-#pragma unroll
-    for (int u = 12; u < 16; ++u) pxv[u] = 0.f;
-    __syncthreads();
-    const CameraLds Q{q0, Q0_CAP, res, q1, Q1_CAP, counts};
-    camera_sh6_lane<WAVES>(pxv, live, px0, cam, (uint32_t)e, d, Q, w, lane);
+    const int n_tasks = n_subap * n_subap * 3;
+    if (d.photon_noise) alias_table_to_lds(pa.tab, pa.words, tab_s, w, WAVES, lane);
     float mx = 0.f;
-    if (live) {
-        const bool lit = valid2d[k] != 0;
+    for (int c = 0; c < chunks; ++c) {
+        const int task0 = (blockIdx.x * chunks + c) * 512;
+        if (task0 >= n_tasks) break;                                // (uniform over the workgroup)
+        const int task = task0 + tid;
+        const bool live = task < n_tasks;
+        const int k = (live ? task : 0) / 3, q3 = (live ? task : 0) - 3 * k;
+        const int li = k / n_subap, lj = k - li * n_subap;
+        const uint32_t px0 = (uint32_t)((li * 6) * cam + lj * 6 + q3);
+        float* fr = frame + (size_t)e * cam * cam + px0;
+        f32x16s pxv;
 #pragma unroll
         for (int u = 0; u < 6; ++u) {
-            fr[(size_t)u * cam] = pxv[u];
-            fr[(size_t)u * cam + 3] = pxv[6 + u];
-            if (lit) {
-                mx = pxv[u] > mx ? pxv[u] : mx;
-                mx = pxv[6 + u] > mx ? pxv[6 + u] : mx;
+            pxv[u] = live ? fr[(size_t)u * cam] : 0.f;
+            pxv[6 + u] = live ? fr[(size_t)u * cam + 3] : 0.f;
+        }
+#pragma unroll
+        for (int u = 12; u < 16; ++u) pxv[u] = 0.f;
+        if (c == 0) __syncthreads();                                // vmcnt(0) + barrier: every wave's share of the table has landed
+        camera_sh6_lane(pxv, live, px0, cam, (uint32_t)e, d, tab_s, pa.lmax);
+        if (live) {
+            const bool lit = valid2d[k] != 0;
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                fr[(size_t)u * cam] = pxv[u];
+                fr[(size_t)u * cam + 3] = pxv[6 + u];
+                if (lit) {
+                    mx = pxv[u] > mx ? pxv[u] : mx;
+                    mx = pxv[6 + u] > mx ? pxv[6 + u] : mx;
+                }
             }
         }
     }
@@ -119,7 +122,8 @@ __global__ void k_zero(T* p, int n) {
 
 template <typename T>
 int launch_detector(T* frame, T* wfs_max, const uint8_t* valid2d, int n_env, int cam, int n_subap, const DetectorCfg& d,
-                    hipStream_t st) {
+                    const PoissonAlias& pa, hipStream_t st) {
+    if (d.active && d.photon_noise && (!pa.tab || pa.lmax < palias::kCoarseStep)) return fail("camera: the photon-noise tables are missing");
     if (!d.active) return 0;
     if (valid2d) hipLaunchKernelGGL(k_zero<T>, dim3(cdiv(n_env, 256)), dim3(256), 0, st, wfs_max, n_env);
     const int sh6 = (valid2d && n_subap > 0 && cam == 6 * n_subap) ? 1 : 0;
@@ -127,20 +131,25 @@ int launch_detector(T* frame, T* wfs_max, const uint8_t* valid2d, int n_env, int
         return fail("camera noise on a Shack-Hartmann frame needs 6 or a multiple of 4 pixels per lenslet, got %d", cam / n_subap);
     if constexpr (sizeof(T) == 4) {
         if (sh6) {
-            hipLaunchKernelGGL(k_detector_sh6, dim3(cdiv(n_subap * n_subap * 3, 256), n_env), dim3(256), 0, st, frame, wfs_max, valid2d, cam,
-                               n_subap, d);
+            const int n_runs = cdiv(n_subap * n_subap * 3, 512);
+            int chunks = (int)(((size_t)n_runs * n_env) / 2048);   // >= 2048 workgroups where there is that much work, <= 8 runs each
+            chunks = chunks < 1 ? 1 : (chunks > 8 ? 8 : chunks);
+            PoissonAlias pl = pa;
+            pl.words = pa.words < palias::kMaxWords ? pa.words : palias::kMaxWords;
+            hipLaunchKernelGGL(k_detector_sh6, dim3(cdiv(n_runs, chunks), n_env), dim3(512), 0, st, frame, wfs_max, valid2d, cam, n_subap, d,
+                               pl, chunks);
             AO_HIP(hipGetLastError());
             return 0;
         }
     }
     const int n_quads = sh6 ? n_subap * n_subap * 9 : cam * ((cam + 3) / 4);
     const int chunks = cdiv(n_quads, 256 * 2) < 1 ? 1 : cdiv(n_quads, 256 * 2);
-    hipLaunchKernelGGL(k_detector<T>, dim3(chunks, n_env), dim3(256), 0, st, frame, wfs_max, valid2d, cam, n_subap, d, n_quads, sh6);
+    hipLaunchKernelGGL(k_detector<T>, dim3(chunks, n_env), dim3(256), 0, st, frame, wfs_max, valid2d, cam, n_subap, d, pa, n_quads, sh6);
     AO_HIP(hipGetLastError());
     return 0;
 }
 
-template int launch_detector<float>(float*, float*, const uint8_t*, int, int, int, const DetectorCfg&, hipStream_t);
-template int launch_detector<double>(double*, double*, const uint8_t*, int, int, int, const DetectorCfg&, hipStream_t);
+template int launch_detector<float>(float*, float*, const uint8_t*, int, int, int, const DetectorCfg&, const PoissonAlias&, hipStream_t);
+template int launch_detector<double>(double*, double*, const uint8_t*, int, int, int, const DetectorCfg&, const PoissonAlias&, hipStream_t);
 
 }  // namespace ao

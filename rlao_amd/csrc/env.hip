@@ -132,6 +132,9 @@ struct AoEnv {
     int pyr_chunk = 1;
     void* vbuf = nullptr;                   // [E][A]
     DetectorCfg det{};                      // aoenv_set_detector(); det.active = 0: ideal camera
+    uint32_t* alias_tab = nullptr;          // alias tables of the photon-noise sampler (poisson_alias.hpp), whole
+    int alias_words = 0;
+    PoissonAlias alias() const { return PoissonAlias{alias_tab, alias_words, palias::kCoarseStep * palias::kMaxCoarseRows}; }
     bool det_seeded = false;                // a seed has been set: the frame counter survives later aoenv_set_detector calls
     void* ret_acc = nullptr;                // caller-owned [E] episode-return accumulator (aoenv_set_return_accumulator)
     std::vector<void*> allocs;
@@ -481,7 +484,7 @@ int apply_detector(AoEnv* env, bool sh, hipStream_t st) {
     env->det.frame_counter += 1;
     AO_PROF(env, DETECTOR, st);
     return launch_detector<T>(env->as<T>(env->frame), env->as<T>(env->wfs_max), sh ? env->valid2d : nullptr, env->E,
-                              env->c.cam_res, env->nSub, env->det, st);
+                              env->c.cam_res, env->nSub, env->det, env->alias(), st);
 }
 
 template <typename T>
@@ -630,7 +633,6 @@ template <>
 bool fused_step_ok<float>(const AoEnv* env) {
     return env->use_fused_step && env->use_fast_wfs && env->use_mfma && env->use_fused_tail && env->c.wfs_type == AOENV_WFS_SH && env->c.dm_separable && env->n_modes > 0 &&
            env->c.max_group == 1 && env->L > 0 && env->c.cam_res == env->R && env->debug_ablate == 0 &&
-           !(env->det.active && env->det.dark_e >= 10.f) &&      // (the fused camera draws the dark electrons by inversion only)
            step_fused_supported(env->R, env->nSub, env->nVal, env->nAct, env->n_modes) != 0;
 }
 
@@ -708,6 +710,7 @@ int run_fused_step<float>(AoEnv* env, int i, const void* d_action, void* d_obs, 
     a.gya = env->gya;
     if (env->det.active) env->det.frame_counter += 1;              // every measurement is a new frame of the noise streams
     a.det = env->det;
+    a.pa = env->alias();
     for (int l = 0; l < env->L; ++l) {
         a.ring_x[l] = env->ring_pending[l] ? static_cast<const float*>(env->ring_src[l]) : nullptr;
         a.ring_splits[l] = env->ring_pending[l];
@@ -953,6 +956,13 @@ int aoenv_create(const AoCfg* cfg, int device, AoEnv** out) {
         A_(&e->pyr_t2, E * e->pyr_chunk * N * N * 2 * z);
     }
     A_(&e->vbuf, (size_t)kMaxSplits * E * e->A * z);
+    {
+        const PoissonAliasHost& ph = poisson_alias_host();
+        e->alias_words = (int)ph.tab.size();
+        A_((void**)&e->alias_tab, ph.tab.size() * 4);
+        if (!rc && hipMemcpy(e->alias_tab, ph.tab.data(), ph.tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+            rc = fail("aoenv_create: upload of the photon-noise tables failed");
+    }
     if (rc) { aoenv_destroy(e); return rc; }
     for (int l = 0; l < e->L; ++l) {
         e->mt_cur[l] = e->mt_state + (size_t)l * E * kMtN;

@@ -66,6 +66,7 @@ constexpr int NV4 = (WR * WC4 + 63) / 64;              // 16-byte staging loads 
 
 struct StepLds {
     int cimg, s1, mapt, slot, e0, sl, img, total;      // offsets in 4-byte words
+    int tab, tab_cap;                                  // the camera's alias tables (stage B) and the words there are for them
 };
 
 static StepLds step_lds_layout(int n_act, int n_subap, int n_valid, int n_modes) {
@@ -74,16 +75,20 @@ static StepLds step_lds_layout(int n_act, int n_subap, int n_valid, int n_modes)
     const int nAp = (n_act + 3) & ~3, SS = nAp + 1;
     int o = 0;
     auto take = [&](int words) { const int at = o; o += (words + 3) & ~3; return at; };
-    // the slopes and the observation image / modal coefficients of stages B-C live where Gy C (s1) was: s1 is dead once
-    // stage A is over (the barrier in front of stage B), and 32 actuators across (two chained DMs) would not fit otherwise
+    // What stage A leaves behind is dead at the barrier in front of stage B: the command image, Gy C (s1) and the waves' layer
+    // tiles make room for the alias tables of the camera's photon draw (poisson_alias.hpp; copied there by direct loads while the
+    // spots are computed).  The slopes and the observation image / modal coefficients of stages B-C live where the lenslet
+    // fields (E0) were: written only behind the barrier that follows the spots of every wave.
     const int sl_words = (2 * n_valid + 3) & ~3, img_words = n_act * n_act + n_modes;
     L.cimg = take(n_act * n_act);
-    L.s1 = take(std::max(2 * PR * SS, sl_words + img_words));
-    L.sl = L.s1;
-    L.img = L.s1 + sl_words;
+    L.s1 = take(2 * PR * SS);
     L.mapt = take(16 * WR * WC);
+    L.tab = L.cimg;
+    L.tab_cap = o - L.tab;
     L.slot = take((n_subap * n_subap + 1) / 2);
-    L.e0 = take(2 * n_valid * fast6::EST);
+    L.e0 = take(std::max(2 * n_valid * fast6::EST, sl_words + img_words));
+    L.sl = L.e0;
+    L.img = L.e0 + sl_words;
     L.total = o;
     return L;
 }
@@ -112,12 +117,12 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
     float* mapt = lds + L.mapt + w_ * (WR * WC);                   // [WR][WC] this wave's private layer tile
     short* slot_s = reinterpret_cast<short*>(lds + L.slot);      // [nSub^2] lenslet -> compact valid index or -1
     cplx<float>* E0 = reinterpret_cast<cplx<float>*>(lds + L.e0);    // [nValid][EST]
-    float* sl = lds + L.sl;                                      // [2 nValid] slopes            (aliases s1: stages B-C)
-    float* img_s = lds + L.img;                                  // [nA^2 + n_modes]             (aliases s1: stage C)
+    float* sl = lds + L.sl;                                      // [2 nValid] slopes            (aliases E0: behind the threshold barrier)
+    float* img_s = lds + L.img;                                  // [nA^2 + n_modes]             (aliases E0: stage C)
+    const uint32_t* tab_s = reinterpret_cast<const uint32_t*>(lds + L.tab);   // camera: alias tables (alias cimg, s1, the layer tiles: stage B)
     __shared__ double red[4][16];
     __shared__ double red_tail[16];
     __shared__ float red_mx[16];
-    __shared__ int q_count_s[17];                                // stage B camera: entries of the 16 wave segments of Q0, of Q1
 
     const int e = blockIdx.x;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
@@ -159,7 +164,6 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
     for (int i = tid; i < 2 * PR * SS; i += 1024) s1[i] = 0.f;
     if (tid < n_sub * n_sub) slot_s[tid] = slot_v;
     for (int i = tid + 1024; i < n_sub * n_sub; i += 1024) slot_s[i] = a.slot_of[i];
-    if (tid < 17) q_count_s[tid] = 0;
     lds_barrier();
     if (has_act) cimg[act_px] = act_c;
     float breg[2][KS];
@@ -441,9 +445,12 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
         red[2][w] = s_res;
         red[3][w] = q_res;
     }
-    lds_barrier();                                             // E0 complete, red complete, s1 dead
+    lds_barrier();                                             // E0 complete, red complete, cimg / s1 / layer tiles dead
     AO_STAMP(14);
     AO_WSTAMP(4);
+    // the camera's tables on their way into LDS (no registers, nobody waits): they land while the spots are computed
+    const bool cam_photons = a.det.active && a.det.photon_noise;
+    if (cam_photons) alias_table_to_lds(a.pa.tab, a.pa.words, reinterpret_cast<uint32_t*>(lds + L.tab), w, 16, lane);
     if (tid == 1023) {                                           // an idle lane: runs beside the spots of the other waves
         double v[4];
         for (int c = 0; c < 4; ++c) {
@@ -486,9 +493,11 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
         for (int i = 0; i < 6; ++i) { pxv[i] = Ia[i]; pxv[6 + i] = Ib[i]; }
 #pragma unroll
         for (int i = 12; i < 16; ++i) pxv[i] = 0.f;
-        const int q0_cap = (L.slot - L.s1) / 4;
-        const CameraLds Q{reinterpret_cast<f32x4d*>(lds + L.s1), q0_cap, lds + L.e0, lds + L.e0 + q0_cap, (L.total - L.e0 - q0_cap) / 3, q_count_s};
-        camera_sh6_lane<16>(pxv, ok, (uint32_t)((li * 6) * R + lj * 6 + q3), R, (uint32_t)e, a.det, Q, w, lane);
+        if (cam_photons) {                                        // this wave's share of the tables has landed; then everybody's
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_barrier();
+        }
+        camera_sh6_lane(pxv, ok, (uint32_t)((li * 6) * R + lj * 6 + q3), R, (uint32_t)e, a.det, tab_s, a.pa.lmax);
 #pragma unroll
         for (int i = 0; i < 6; ++i) { Ia[i] = pxv[i]; Ib[i] = pxv[6 + i]; }
     }
@@ -503,9 +512,6 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
         }
     }
     AO_STAMP(15);
-    // (aliases s1 -- and the camera's queue Q0, which is finished with here) zero at non-actuators: vec_to_img.  Stage C writes
-    // the actuators' values two barriers from here.
-    for (int i = tid; i < nA * nA; i += 1024) img_s[i] = 0.f;
     if (a.det.active && (a.det.dark_e > 0.f || a.det.readout_noise != 0.f)) {
         // the camera also reads out the pixels of the lenslets that are not valid (no light): dark + read-out noise, ADC
         const float rtab = recip_table_lane();
@@ -516,7 +522,7 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
                 uint32_t pix[4];
                 sh6_quad_pixels(j, i2 * 6, j2 * 6, R, pix);
                 f32x4d v = {0.f, 0.f, 0.f, 0.f};
-                detector_quad<false>(v, pix, pix[0], (uint32_t)e, a.det, rtab);
+                detector_quad<false>(v, pix, pix[0], (uint32_t)e, a.det, rtab, a.pa);
 #pragma unroll
                 for (int s4 = 0; s4 < 4; ++s4) a.frame[pix0 + pix[s4]] = v[s4];
             }
@@ -557,6 +563,9 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
 #pragma unroll
     for (int q = 1; q < 16; ++q) mx = red_mx[q] > mx ? red_mx[q] : mx;
     if (tid == 0) a.wfs_max[e] = mx;
+    // (aliases E0: every wave has its spots by now) zero at non-actuators: vec_to_img.  Stage C writes the actuators' values two
+    // barriers from here.
+    for (int i = tid; i < nA * nA; i += 1024) img_s[i] = 0.f;
     const float cut = a.sc.threshold * mx;
     {
         float norm = 0.f, m0 = 0.f, m1 = 0.f;
@@ -685,8 +694,14 @@ int step_fused_supported(int R, int n_subap, int n_valid, int n_act, int n_modes
     return (size_t)L.total * 4 <= 160 * 1024 - 1024 ? 1 : 0;     // static __shared__ of the kernel: < 1 KB
 }
 
-int launch_env_step(const StepArgs& a, hipStream_t st) {
+int launch_env_step(const StepArgs& a_in, hipStream_t st) {
+    StepArgs a = a_in;
     const StepLds L = step_lds_layout(a.k.n_act, a.n_subap, a.n_valid, a.n_modes);
+    if (a.det.active && a.det.photon_noise) {                     // as much of the alias tables as fits where stage A's buffers were
+        if (!a.pa.tab) return fail("fused step: the photon-noise tables are missing");
+        poisson_alias_host().prefix(std::min(L.tab_cap, a.pa.words), &a.pa.words, &a.pa.lmax);
+        if (a.pa.lmax < palias::kCoarseStep) return fail("fused step: no room for the photon-noise tables (%d words)", L.tab_cap);
+    }
     const size_t lds = (size_t)L.total * 4;
     const int v = a.k.n_act <= 24 ? 0 : 1;
     const bool pe = a.k.pa.env_taps != nullptr;

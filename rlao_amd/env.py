@@ -741,8 +741,11 @@ class BatchedAOEnv:
     def reset_soft(self):
         """MAIN/OOPAOEnv/OOPAOEnv.py:82-86."""
         self.action_buffer = []
-        L.check(self._shard.lib.aoenv_reset_soft(self._shard.h, C.c_void_p(self._obs.data_ptr()), C.c_void_p(self._stream())))
-        return self._out(self._obs.clone())
+        # a NEW tensor, like step(): the observation handed out by the previous step (a trainer may have kept it) is not written to
+        obs = _torch().empty_like(self._obs)
+        L.check(self._shard.lib.aoenv_reset_soft(self._shard.h, C.c_void_p(obs.data_ptr()), C.c_void_p(self._stream())))
+        self._obs = obs
+        return self._out(obs)
 
     def reset(self):
         raise NotImplementedError("reset() re-runs set_params() with no arguments in the reference and fails there "
@@ -810,6 +813,9 @@ class BatchedAOEnv:
         the step epilogue; returns the last (obs, reward, strehl).  ``reset_soft()`` (or a previous step) must
         have produced the current observation."""
         g = float(self.gainCL if gain is None else gain)
+        # the loop runs in place on the observation: on private copies, never on tensors step() / reset_soft() have handed out
+        self._obs = self._obs.clone()
+        self._reward, self._strehl = _torch().empty_like(self._reward), _torch().empty_like(self._strehl)
         L.check(self._shard.lib.aoenv_run_integrator(
             self._shard.h, int(i0), int(n_steps), g, C.c_void_p(self._obs.data_ptr()), None,
             C.c_void_p(self._reward.data_ptr()), C.c_void_p(self._strehl.data_ptr()), C.c_void_p(self._stream())))
@@ -857,7 +863,7 @@ class BatchedAOEnv:
         sh.upload_state(L.B_DM_PREV, state.get("dm_prev", state["coefs"]), st)
         sh.upload_state(L.B_SIGNAL, state["signal"], st)
         sh.upload_state(L.B_COUNTERS, state["counters"], st, dtype=np.uint32)
-        self._obs.copy_(_torch().as_tensor(state["obs"], device=self.device, dtype=self.tdtype))
+        self._obs = _torch().as_tensor(state["obs"]).to(device=self.device, dtype=self.tdtype).clone()   # (never into a handed-out tensor)
 
     def accumulate_returns(self, tensor):
         """Attach a device tensor [n_envs] (env dtype) to which every step adds its reward (None detaches): the

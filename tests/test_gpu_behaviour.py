@@ -113,6 +113,7 @@ def test_run_integrator_equals_stepping():
     env = BatchedAOEnv(n_envs=4, device=0, dtype="f32")
     env.set_params(SMALL, camera="ideal", wfs_type="shackhartmann", gainCL=0.4)
     a = _run(env, 10, 3, gain=0.4)
+    total_stepped, residual_stepped = env.total[:10].copy(), env.residual[:10].copy()
     env.generate_new_phase_screen(3)
     env.dm.coefs = 0
     env.dm_prev = 0
@@ -122,7 +123,10 @@ def test_run_integrator_equals_stepping():
     torch.cuda.synchronize()
     np.testing.assert_allclose(obs.cpu().numpy(), a[-1][0].cpu().numpy(), atol=1e-6)
     np.testing.assert_allclose(sr.cpu().numpy(), a[-1][3].cpu().numpy(), atol=1e-6)
-    np.testing.assert_allclose(env.total[:10], env.total[:10])
+    # the telemetry of the on-device loop against the stepped run's (env.total / env.residual, OOPAOEnv.py:497, 522)
+    np.testing.assert_allclose(env.total[:10], total_stepped, rtol=1e-6)
+    np.testing.assert_allclose(env.residual[:10], residual_stepped, rtol=1e-6)
+    assert (total_stepped > 0).all() and (residual_stepped > 0).all()
     # the on-device episode return (aoenv_set_return_accumulator) is the sum of the step rewards
     ret = torch.zeros(4, device=env.device, dtype=env.tdtype)
     env.generate_new_phase_screen(3)
@@ -519,3 +523,30 @@ def test_fused_step_query_tells_which_path_runs():
             L.check(env._shard.lib.aoenv_set_option(env._shard.h, L.OPT_FUSED_STEP, 0))
             assert env.fused_step is False
         env.close()
+
+
+def test_tensors_handed_out_by_step_survive_the_next_episode():
+    """step() hands out new tensors (a replay buffer may keep them, as it keeps the reference's arrays): the episode prologue
+    (reset_soft), the on-device loop (run_integrator) and a restored checkpoint must not write into them."""
+    import torch
+    from rlao_amd.env import BatchedAOEnv
+    env = BatchedAOEnv(n_envs=3, device=0, dtype="f32")
+    env.set_params(SMALL, camera="ideal", wfs_type="shackhartmann", gainCL=0.4)
+    env.generate_new_phase_screen(3)
+    obs0 = env.reset_soft()
+    obs, frame, rew, sr, done, info = env.step(0, 0.4 * obs0)
+    kept = [t.clone() for t in (obs0, obs, frame, rew, sr, env.SR[-1])]
+    state = env.get_state()
+    env.generate_new_phase_screen(4)
+    env.dm.coefs = 0
+    env.measure()
+    obs1 = env.reset_soft()
+    env.run_integrator(0, 5)
+    o2, _, r2, s2, _, _ = env.step(5, 0.1 * obs1)
+    env.set_state(state)
+    env.run_integrator(1, 3)
+    torch.cuda.synchronize()
+    for t, k in zip((obs0, obs, frame, rew, sr, env.SR[0]), kept):
+        assert torch.equal(t, k)
+    assert not torch.equal(o2, obs) and o2.data_ptr() != obs.data_ptr()
+    env.close()

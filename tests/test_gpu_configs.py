@@ -142,6 +142,13 @@ def test_c4_elt_measurement_matches_reference_and_ring_matches_oracle(golden_dir
                 np.testing.assert_allclose(env.reference_centroids[:nv], ref2d[:ns][valid], atol=1e-12)
                 np.testing.assert_allclose(env.reference_centroids[nv:], ref2d[ns:][valid], atol=1e-12)
                 np.testing.assert_allclose(env.slopes_units, float(g["slopes_units"]), rtol=1e-9)
+                # the zonal interaction matrix: first / middle / last measurement group of the 5209-column calibration against the
+                # reference's InteractionMatrix (pokes of a group share the centroid threshold; the last group is one actuator)
+                idx = g["imat_idx"]
+                assert idx[0] == 0 and idx[-1] == env.nValidAct - 1 and len(idx) == 13
+                scale = float(np.abs(g["imat_cols"]).max())
+                np.testing.assert_allclose(env.imat[:, idx], g["imat_cols"], atol=1e-10 * scale)
+                assert np.abs(env.imat).max() < 1.01 * scale * 1.5
             # (a) one measurement of the recorded wave-front
             env._shard.set_atm_opd(np.broadcast_to(opd_in.reshape(1, -1), (n_envs, R * R)))
             env._shard.set_coefs(np.broadcast_to(g["coefs"][None], (n_envs, 5209)))
@@ -180,6 +187,69 @@ def test_c4_elt_measurement_matches_reference_and_ring_matches_oracle(golden_dir
                 assert abs(buff[0, 0]) < 1 and env._shard.download(L.B_XI, (n_envs, env._atm_tables.n_inner + 1940)).any()
         finally:
             env.close()
+
+
+def test_c4_elt_closed_loop_matches_oracle():
+    """BASELINE configs[3] in CLOSED LOOP against the oracle at R = 480 (5209 actuators, 10048 slopes, 300 modes): the factored
+    reconstruction t = M s, v = M2C t of the batched path, the epilogue / integrator, the telemetry over 181 k pupil pixels and a
+    ring extrusion of the 484^2 layer, float64 and float32 shards of two envs with their own seeds.  The oracle gets the env's
+    GPU-calibrated modal command matrix (whose zonal columns the test above pins against the reference) and its separable DM."""
+    import torch
+    from oracle import ao_oracle as O                       # checker only
+    from rlao_amd.env import BatchedAOEnv
+    R, steps = 480, 6
+    geom = O.LayerGeometry(R, 39.0, 30.0)
+    AB = geom.AB(0.13)                                           # the ring operators handed to both sides (host pinv differs at 1e-9)
+    base, worst = None, {}
+    for dtype, tol in (("f64", dict(obs=2e-7, sig=1e-9, res=1e-6, sr=1e-9, rew=1e-9)),
+                       ("f32", dict(obs=2e-3, sig=2e-3, res=2e-2, sr=2e-5, rew=2e-4))):
+        env = BatchedAOEnv(n_envs=2, device=0, dtype=dtype)
+        try:
+            env.set_params(C4, camera="ideal", wfs_type="shackhartmann", atm_AB=AB)
+            assert not env.fused_step and env.nValidAct == 5209 and env.modal_CM.shape == (300, 10048)
+            if base is None:
+                base = O.OracleEnv(resolution=R, diameter=39.0, n_subap=80, r0=0.13, L0=30.0, windSpeed=C4["windSpeed"],
+                                   windDirection=C4["windDirection"], fractionalR0=[1.0], altitude=[0.0], m2c=env.M2C_CL, n_modes=300,
+                                   modal_cm=env.modal_CM, dm_dense=False, geom_AB=(geom,) + tuple(AB))
+            env.generate_new_phase_screen(17)
+            env.dm.coefs = 0
+            env.dm_prev = 0
+            env.measure()
+            obs = env.reset_soft()
+            orcs = []
+            for k in range(2):
+                o = copy.deepcopy(base)
+                o.new_episode(17 + k)
+                np.testing.assert_allclose(obs[k].cpu().numpy(), o.reset_soft(), atol=tol["obs"])
+                orcs.append(o)
+            crossed = False
+            b0 = env._shard.get_buff(1).copy()
+            for i in range(steps):
+                act = 0.5 * obs
+                obs, frame, rew, sr, _, _ = env.step(i, act)
+                b1 = env._shard.get_buff(1).copy()
+                crossed |= bool((np.abs(b1) < np.abs(b0)).any())   # an accumulator wrapped: a pixel was crossed, a ring extruded
+                b0 = b1
+                sig = env.wfs.signal
+                for k, o in enumerate(orcs):
+                    oo, of, orw, osr, _, _ = o.step(i, act[k].double().cpu().numpy())
+                    d = dict(obs=np.abs(obs[k].cpu().numpy() - oo).max(), sig=np.abs(sig[k] - o.wfs.signal).max(),
+                             sr=abs(float(sr[k]) - osr), rew=abs(float(rew[k]) - orw) / abs(orw))
+                    for q, v in d.items():
+                        worst[(dtype, q)] = max(worst.get((dtype, q), 0.0), float(v))
+                        assert v <= tol[q], (dtype, q, i, k, v)
+                    np.testing.assert_allclose(frame[k].cpu().numpy(), of, atol=(1e-9 if dtype == "f64" else 5e-5) * of.max())
+            assert crossed
+            res, tot = env.residual[:steps], env.total[:steps]
+            for k, o in enumerate(orcs):
+                worst[(dtype, "res")] = max(worst.get((dtype, "res"), 0.0), float(np.abs(res[:, k] - o.residual[:steps]).max()))
+                np.testing.assert_allclose(res[:, k], o.residual[:steps], atol=tol["res"])
+                np.testing.assert_allclose(tot[:, k], o.total[:steps], atol=tol["res"])
+            assert float(np.abs(obs[0].cpu().numpy() - obs[1].cpu().numpy()).max()) > 0
+        finally:
+            env.close()
+    if os.environ.get("AO_PARITY_REPORT"):
+        print("C4 closed loop, measured maxima:", {f"{a}:{b}": v for (a, b), v in sorted(worst.items())})
 
 
 def test_c2_geometry_1000_envs_ragged_shard():

@@ -55,7 +55,7 @@ def test_photon_noise_is_poisson_and_reproducible():
     ratio = var[lit] / ideal[lit]
     assert abs(ratio.mean() - 1) < 0.03
     assert (a == np.floor(a)).all() and a.min() >= 0
-    # faint pixels too (sequential-inversion branch): mean of the whole frame
+    # faint pixels too: mean of the whole frame
     assert abs(a.mean() - ideal.mean()) < 5 * np.sqrt(ideal.mean() / a.size) + 1e-3 * ideal.mean()
     # every measurement is a new frame of the noise stream; a new env with the same seed replays the same stream
     b = _frames(env)
@@ -72,12 +72,13 @@ def test_photon_noise_is_poisson_and_reproducible():
     env.close()
 
 
-def test_photon_counts_follow_the_poisson_law_in_both_samplers():
+def test_photon_counts_follow_the_poisson_law_in_every_brightness_class():
     """Distribution test of the photon draw, per brightness class: for X ~ Poisson(lam) and V ~ U(0, 1) independent,
     F(X - 1) + V p(X) is uniform on (0, 1) (randomised probability-integral transform), whatever lam each pixel has.  Pooled over
-    the pixels of a class x 256 envs x 4 frames: chi-square of a 64-bin histogram and the Kolmogorov-Smirnov distance.  Classes
-    below 10 photons are drawn by lock-step inversion, from 10 on by PTRS (squeeze in registers, queue passes): both are exact
-    samplers, so no approximation error is allowed for."""
+    the pixels of a class x 256 envs x 4 frames: chi-square of a 64-bin histogram and the Kolmogorov-Smirnov distance.  Every class
+    goes through the alias sampler of poisson_alias.hpp (below 32 photons: fine table + remainder; above: + the coarse table),
+    exact to the 2^-23 quantisation of its thresholds, so no approximation error is allowed for.  (tests/test_poisson_alias.py
+    drives the sampler directly, incl. the PTRS hand-over above 1024 photons.)"""
     from scipy import stats
     env = _env(256)
     ideal = _frames(env)[0]

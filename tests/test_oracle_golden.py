@@ -169,6 +169,21 @@ def test_c4_elt_shack_hartmann_measurement(golden_dir):
     np.testing.assert_allclose(wfs.frame[::8], g["frame_rows"], atol=1e-8 * float(g["frame_max"]))
     np.testing.assert_allclose(wfs.frame.sum(axis=0), g["frame_colsum"], rtol=1e-10)
     np.testing.assert_allclose(wfs.frame.sum(axis=1), g["frame_rowsum"], rtol=1e-10)
+    # three measurement groups of the reference's 5209-column zonal InteractionMatrix (pokes of a group share the centroid threshold)
+    idx, cols = g["imat_idx"], g["imat_cols"]
+    stroke = wl / 16
+    groups = [idx[idx // 6 == q] for q in np.unique(idx // 6)]
+    assert [len(q) for q in groups] == [6, 6, 1]
+    for grp in groups:
+        phases = []
+        for a in grp:
+            ci = np.zeros((ns + 1) ** 2)
+            ci[np.flatnonzero(dm["validAct"])[a]] = stroke
+            phases.append((dm["gy"] @ ci.reshape(ns + 1, ns + 1) @ dm["gx"].T) * 2 * np.pi / wl)
+        gmax = max(wfs.spots(ph)[wfs.valid_1d].max() for ph in phases)
+        for a, ph in zip(grp, phases):
+            col = cols[:, list(idx).index(a)]
+            np.testing.assert_allclose(wfs.measure(ph, group_max=gmax) / stroke, col, atol=1e-9 * np.abs(cols).max())
 
 
 def test_second_episode_keeps_dm_prev(golden_dir):
@@ -230,3 +245,21 @@ def test_two_chained_dms_match_reference(golden_dir):
         np.testing.assert_allclose(opd, g["opd"][k], rtol=0, atol=1e-18)
         sig = env.wfs.measure(opd * 2 * np.pi / env.wavelength)
         np.testing.assert_allclose(sig, g["signal"][k], rtol=0, atol=1e-10)
+
+
+def test_oracle_env_with_separable_dm_equals_dense():
+    """OracleEnv(dm_dense=False) -- the form the ELT-size closed-loop test uses, where dm.modes would be 9.6 GB -- is the same
+    loop as the dense one."""
+    kw = dict(resolution=24, diameter=1.6, n_subap=4, n_modes=8)
+    dense = O.OracleEnv(**kw)
+    sep = O.OracleEnv(m2c=dense.M2C, modal_cm=dense.modal_cm, dm_dense=False, **kw)
+    cf = np.random.RandomState(2).normal(size=dense.nValidAct) * 1e-7
+    np.testing.assert_allclose(sep.dm_opd(cf), dense.dm_opd(cf), atol=1e-21)
+    for e in (dense, sep):
+        e.new_episode(5)
+    od, os_ = dense.reset_soft(), sep.reset_soft()
+    for i in range(6):
+        od, fd, rd, sd, _, _ = dense.step(i, 0.5 * od)
+        os_, fs, rs_, ss, _, _ = sep.step(i, 0.5 * os_)
+        np.testing.assert_allclose(os_, od, atol=1e-9)
+        np.testing.assert_allclose(ss, sd, atol=1e-12)
