@@ -42,6 +42,11 @@ CONFIGS = {
                wfs="pyramid", envs=1024, controller="policy",
                geo=dict(diameter=8.0, nSubaperture=40, nPixelPerSubap=6, r0=0.13, L0=30.0, windSpeed=[10.0], windDirection=[72.0],
                         fractionalR0=[1.0], altitude=[0.0], nModes=50, modulation=0.0)),
+    "C3M": dict(label="8m / 40x40 Pyramid WFS with modulation 3 lambda/D (nTheta = 20), 256 batched envs, integrator closed loop "
+                      "(SURVEY.md 8a A6 / 8d: the x20 FFT term)",
+                wfs="pyramid", envs=256, controller="integrator",
+                geo=dict(diameter=8.0, nSubaperture=40, nPixelPerSubap=6, r0=0.13, L0=30.0, windSpeed=[10.0], windDirection=[72.0],
+                         fractionalR0=[1.0], altitude=[0.0], nModes=50, modulation=3.0)),
     "C4": dict(label="ELT-scale 39m, 80x80 Shack-Hartmann, 4096 envs over 8 GPUs = 512 per GPU (BASELINE.json configs[3])",
                wfs="shackhartmann", envs=512, controller="integrator",
                geo=dict(diameter=39.0, nSubaperture=80, nPixelPerSubap=6, r0=0.13, L0=30.0, windSpeed=[10.0], windDirection=[72.0],
@@ -54,8 +59,15 @@ CONFIGS = {
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA = the f32 vector rate
-# rocprofv3 --pmc passes of this command (scripts/pmc_collect.sh -> scripts/pmc_to_json.py), one file per camera setting
-PMC_FILES = {"papyrus": os.path.join(REPO, "profiles", "r02_c2_pmc.json"), "ideal": os.path.join(REPO, "profiles", "r02_c2_ideal_pmc.json")}
+# rocprofv3 --pmc passes of this command (scripts/pmc_collect.sh -> scripts/pmc_to_json.py), one file per camera setting, and of the
+# BASELINE configs' shards (scripts/prof_configs.sh): `roofline.traffic` is read from these COMMITTED passes (a benchmark run under
+# the driver cannot collect counters itself), never measured in the run that prints the line
+PMC_FILES = {"papyrus": os.path.join(REPO, "profiles", "r03_c2_pmc.json"), "ideal": os.path.join(REPO, "profiles", "r03_c2_ideal_pmc.json"),
+             **{c: os.path.join(REPO, "profiles", f"r03_{c}_pmc.json") for c in ("C3", "C3M", "C4", "C5")}}
+# the kernels behind every profiled stage of aoenv_profile (names as scripts/pmc_to_json.py shortens them)
+STAGE_KERNELS = {"env_step": ["env_step"], "phase": ["phase", "dm_rows"], "sh_spots": ["sh_spots"], "detector": ["detector_sh6", "detector"],
+                 "pyramid": ["pyr_rows", "pyr_cols", "pyr_rows_inv", "pyr_slopes"], "sh_centroid": ["sh_centroid"], "sh_tail": ["sh_tail"],
+                 "gemm_ring": ["ring_gemm_draw_ahead", "gemm_mfma"], "recon_finish": ["recon_finish"]}
 CAMERA_NOTE = {"papyrus": "photon (Poisson) noise on every WFS pixel: the reference env's default camera (OOPAOEnv.py:379)",
                "razor": "Razor camera: photon + dark + read-out noise, QE 0.56, FWC 1e4, 10-bit ADC (OOPAOEnvRazor.py:243-250, 332-333)",
                "ideal": "ideal detector (the parity configuration)"}
@@ -213,15 +225,40 @@ def mfma_flops_per_env_step(env):
     return {"dm": dm, "recon": rec, "ring": ring, "total": dm + rec + ring}
 
 
-def load_pmc(n_envs, camera):
+def load_pmc(n_envs, which, camera="papyrus"):
+    """The committed counter summary of this workload (`which`: a camera name for the headline, else a config name), or None."""
     try:
-        with open(PMC_FILES[camera]) as f:
+        with open(PMC_FILES[which]) as f:
             d = json.load(f)
-        if d.get("n_envs") == n_envs and d.get("camera") == camera:
+        if d.get("n_envs") == n_envs and d.get("camera") == camera and "production" in d:
+            d["file"] = os.path.relpath(PMC_FILES[which], REPO)
             return d
     except Exception:
         pass
     return None
+
+
+def pmc_traffic(pmc, stage, launches_per_invocation=1):
+    """HBM bytes one invocation of `stage` moves, by the counters: sum over the stage's kernels (their production entries)."""
+    if pmc is None:
+        return None, {}
+    parts = {}
+    for b in STAGE_KERNELS.get(stage, [stage]):
+        k = pmc["production"].get(b)
+        if k and "hbm_bytes_per_launch" in pmc["kernels"][k]:
+            parts[k] = pmc["kernels"][k]["hbm_bytes_per_launch"] * launches_per_invocation
+    return (sum(parts.values()) if parts else None), parts
+
+
+def attach_traffic(roof, pmc, launches_per_invocation=1):
+    if roof is None:
+        return
+    t, parts = pmc_traffic(pmc, roof["kernel"], launches_per_invocation)
+    roof["traffic"] = t
+    if t is not None:
+        roof["traffic_source"] = f"committed rocprofv3 --pmc passes of this workload ({pmc['file']}: FETCH_SIZE x 2 + WRITE_SIZE), not measured in this run"
+        roof["traffic_vs_algorithmic"] = t / roof["algorithmic_bytes_per_launch"]
+        roof["traffic_by_kernel"] = parts
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -240,10 +277,13 @@ class Timer:
     def barrier(self):
         if self.world > 1:
             self.dist.barrier()
-        self.torch.cuda.synchronize()
+        if getattr(self.device, "type", "cuda") == "cuda":
+            self.torch.cuda.synchronize()
 
     def regions(self, body, min_seconds, min_repeats=5, max_repeats=2000):
+        """Region times (MAX over the ranks).  self.rank_spread: per region, (fastest, slowest) rank's own time."""
         times = []
+        self.rank_spread = []
         while True:
             self.barrier()
             t0 = time.perf_counter()
@@ -252,8 +292,11 @@ class Timer:
             dt = time.perf_counter() - t0
             if self.world > 1:
                 t = self.torch.tensor([dt], device=self.device, dtype=self.torch.float64)
-                self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-                dt = float(t[0])
+                every = [self.torch.empty_like(t) for _ in range(self.world)]
+                self.dist.all_gather(every, t)
+                own = [float(x[0]) for x in every]
+                self.rank_spread.append((min(own), max(own)))
+                dt = max(own)
             times.append(dt)
             if len(times) >= max_repeats or (len(times) >= min_repeats and sum(times) >= min_seconds):
                 return times
@@ -314,66 +357,100 @@ class ConvPolicy:
                 nn.init.constant_(m.bias, 0)
         self.net = self.net.to(env.device).eval()
 
-    def __call__(self, obs, history):
+    def __call__(self, obs, past_obs, past_act):
+        """obs [n, A, A]; past_obs / past_act [n, n_history - 1, A, A] windows (views of the device ring buffers), newest first"""
         torch = self.torch
         with torch.no_grad():
-            out = self.net(torch.cat([obs.unsqueeze(1), history], dim=1)).clamp(-1, 1).squeeze(1)
+            out = self.net(torch.cat([obs.unsqueeze(1), past_obs, past_act], dim=1)).clamp(-1, 1).squeeze(1)
             vec = out[:, self.xv, self.yv] @ self.F.T
             ret = torch.zeros_like(out)
             ret[:, self.xv, self.yv] = vec
             return ret
 
 
-def bench_config(name, args, torch, timer):
-    """One BASELINE config's per-GPU shard: build, warm up, R regions of K steps, per-kernel profile."""
+def bench_config(name, args, torch, timer, rank=0, world=1):
+    """One BASELINE config's per-GPU shard: build, warm up, R regions of K steps, per-kernel profile.  world > 1 (`--config NAME
+    --gpus N`): every rank steps its own shard of cfg["envs"] envs (global env index = rank * envs + e: atmosphere seeds and camera
+    noise streams), and every timed region ends with the all-gather of the per-env episode returns."""
+    from rlao_amd import dist as aodist
     from rlao_amd.env import BatchedAOEnv
+    from rlao_amd.wrappers import DeviceHistory
     cfg = CONFIGS[name]
     K = min(args.steps, 20)
-    n = cfg["envs"]
+    n = cfg["envs"] if args.envs_per_gpu is None else args.envs_per_gpu
+    n_total = n * world
     t0 = time.perf_counter()
-    env = BatchedAOEnv(n_envs=n, device=timer.device.index, dtype="f32", return_frame=False)
+    env = BatchedAOEnv(n_envs=n, device=timer.device.index, dtype="f32", return_frame=False, env_index_offset=rank * n)
     env.set_params(dict(cfg["geo"], nLoop=12 * K + 64), wfs_type=cfg["wfs"], second_dm=cfg.get("second_dm"), camera="papyrus")
     init_s = time.perf_counter() - t0
     obs = start_episode(env)
-    out = {"workload": cfg["label"], "envs_per_gpu": n, "steps": K, "resolution": env.R, "n_valid_act": env.nValidAct,
+    returns = torch.zeros(n, device=env.device, dtype=env.tdtype)
+    if world > 1:
+        aodist.all_gather_returns(returns, n_total)             # warm the communicator outside the timed regions
+    gathered = {}
+    out = {"workload": cfg["label"], "envs_per_gpu": n, "envs_total": n_total, "steps": K, "resolution": env.R, "n_valid_act": env.nValidAct,
            "n_signal": env.nSignal, "layers": env.param.nLayer, "camera": CAMERA_NOTE["papyrus"], "init_s": round(init_s, 1)}
     if cfg["controller"] == "policy":
         n_history, A = 20, env.nActuator
         policy = ConvPolicy(env, n_history)
-        st = {"obs": obs, "po": torch.zeros(n, n_history - 1, A, A, device=env.device), "pa": torch.zeros(n, n_history - 1, A, A, device=env.device),
-              "ret": torch.zeros(n, device=env.device)}
+        # observation / action histories as mirrored device ring buffers (rlao_amd.wrappers.DeviceHistory): a push is two slot
+        # writes, the policy's input window a view -- no history is rolled or re-concatenated per step
+        hist_o = DeviceHistory(n, n_history - 1, A, env.device)
+        hist_a = DeviceHistory(n, n_history - 1, A, env.device)
+        st = {"obs": obs}
 
         def rollout(i0, k):                                     # MAIN/PO4AO/mbrl.py:64-89 with a leading env dimension
             for t in range(i0, i0 + k):
-                action = policy(st["obs"], torch.cat([st["po"], st["pa"]], dim=1))
+                action = policy(st["obs"], hist_o.window(), hist_a.window())
                 nxt, _, reward, strehl, _, _ = env.step(t, action)
-                st["po"] = torch.cat([st["po"][:, 1:], st["obs"].unsqueeze(1)], dim=1)
-                st["pa"] = torch.cat([st["pa"][:, 1:], action.unsqueeze(1)], dim=1)
-                st["ret"] += reward
+                hist_o.push(st["obs"])
+                hist_a.push(action)
+                returns.add_(reward)
                 st["obs"] = nxt
             return strehl
 
+        def region(r):
+            rollout(8 + (r % 8) * K, K)
+            gathered["returns"] = aodist.all_gather_returns(returns, n_total)
+
         rollout(0, 3)
-        times = timer.regions(lambda r: rollout(8 + (r % 8) * K, K), args.min_seconds, min_repeats=3, max_repeats=200)
+        times = timer.regions(region, args.min_seconds, min_repeats=3, max_repeats=200)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(5):
-            policy(st["obs"], torch.cat([st["po"], st["pa"]], dim=1))
+            policy(st["obs"], hist_o.window(), hist_a.window())
         torch.cuda.synchronize()
         out["controller"] = "ConvPolicy 3 x Conv2d(64), n_history 20, random weights seed 5, evaluated for all envs on the GPU"
         out["policy_ms_per_step"] = 1e3 * (time.perf_counter() - t1) / 5
         prof_run = lambda: rollout(8 + 9 * K, K)               # noqa: E731
         out["mean_strehl"] = float(env._strehl.mean())
+        out["mean_strehl_note"] = "random-weight policy: carries no information about the loop; see integrator_mean_strehl"
+        # the same shard under the integrator (gain 0.5), 2 K steps from a fresh episode: a Strehl that says the loop closes
+        obs = start_episode(env)
+        env.run_integrator(0, 2 * K)
+        out["integrator_mean_strehl"] = float(env._strehl.mean())
     else:
         env.run_integrator(0, 4)
-        times = timer.regions(lambda r: env.run_integrator(8 + (r % 8) * K, K), args.min_seconds, min_repeats=3, max_repeats=500)
+        env.accumulate_returns(returns)
+
+        def region(r):
+            env.run_integrator(8 + (r % 8) * K, K)
+            gathered["returns"] = aodist.all_gather_returns(returns, n_total)
+
+        times = timer.regions(region, args.min_seconds, min_repeats=3, max_repeats=500)
+        env.accumulate_returns(None)
         out["controller"] = "leaky integrator, gain 0.5, on the device"
         prof_run = lambda: env.run_integrator(8 + 9 * K, K)     # noqa: E731
         out["mean_strehl"] = float(env._strehl.mean())
     s = stats(times)
-    out.update(value=n * K / s["median"], unit="env-steps/s", ms_per_step=1e3 * s["median"] / K, repeats=len(times),
-               region_ms={k: 1e3 * v for k, v in s.items()})
+    out.update(value=n_total * K / s["median"], unit="env-steps/s", ms_per_step=1e3 * s["median"] / K, repeats=len(times),
+               region_ms={k: 1e3 * v for k, v in s.items()}, mean_episode_return=float(gathered["returns"].mean()))
+    if world > 1:
+        out["region_ms_per_rank"] = {"fastest_rank_min": 1e3 * min(a for a, _ in timer.rank_spread),
+                                     "slowest_rank_max": 1e3 * max(b for _, b in timer.rank_spread)}
     per_kernel, roof, step_bytes = kernel_profile(env, prof_run, n)
+    nt = getattr(env, "_wfs_n_theta", 1)
+    attach_traffic(roof, load_pmc(n, name), launches_per_invocation=-(-nt // 4) if roof and roof["kernel"] == "pyramid" else 1)
     out["kernels"] = per_kernel
     out["roofline"] = roof
     out["step_roofline"] = {"algorithmic_bytes_per_env_step": step_bytes, "achieved_GBs": step_bytes * n / (s["median"] / K) / 1e9,
@@ -387,12 +464,39 @@ def bench_config(name, args, torch, timer):
     return out
 
 
+def config_headline(args, torch, dist, rank, world, local, cpu):
+    """`--config C3|C3M|C4|C5 [--gpus N]`: that BASELINE config as the one JSON line of the contract (rank 0 prints it)."""
+    timer = Timer(torch, dist, world, torch.device("cuda", local))
+    name = args.config
+    r = bench_config(name, args, torch, timer, rank=rank, world=world)
+    roof = r.get("roofline")
+    line = {"metric": "AO env-steps/sec (batched loops)", "value": r["value"], "unit": "env-steps/s", "n_gpus": world,
+            "steps": r["steps"], "warmup": 4, "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "repeats": r["repeats"], "region_ms": r["region_ms"],
+            "config": {"workload": r["workload"], "name": name, "envs_per_gpu": r["envs_per_gpu"], "envs_total": r["envs_total"],
+                       "resolution": r["resolution"], "n_valid_act": r["n_valid_act"], "n_signal": r["n_signal"], "layers": r["layers"],
+                       "controller": r["controller"], "camera": r["camera"],
+                       "parallelism": f"env-shards x{world}, all-gather of episode returns"},
+            "roofline": roof, "step_roofline": r["step_roofline"], "mfma": r["mfma"], "kernels": r["kernels"],
+            "mean_strehl_last_step": r["mean_strehl"], "mean_episode_return": r["mean_episode_return"]}
+    for k in ("region_ms_per_rank", "integrator_mean_strehl", "policy_ms_per_step", "traffic_vs_algorithmic"):
+        if k in r:
+            line[k] = r[k]
+    if cpu is not None:
+        line["cpu_baseline"] = cpu
+    return line
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--envs-per-gpu", type=int, default=256)
+    ap.add_argument("--envs-per-gpu", type=int, default=None, help="default: 256 (C2) / the config's own per-GPU shard")
+    ap.add_argument("--config", default="C2", type=str.upper, choices=["C2"] + sorted(CONFIGS),
+                    help="the workload of the headline line: C2 (default) = BASELINE configs[1]; C3 / C4 / C5 = BASELINE configs[2..4] "
+                         "as stated (with --gpus 8: 512 resp. 256 envs per GPU), C3M = the modulated Pyramid.  Same timer: K-step "
+                         "regions, all-gather of the episode returns inside each")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--min-seconds", type=float, default=0.6, help="the timed regions of K steps are repeated until they add up to this")
     ap.add_argument("--noise", nargs="?", const="razor", default="photon", choices=["off", "photon", "razor"],
@@ -410,7 +514,7 @@ def main():
 
     rank_env, world_env = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     cpu = None
-    if not args.no_cpu_baseline and rank_env == 0 and world_env == 1:
+    if not args.no_cpu_baseline and rank_env == 0 and world_env == 1 and args.config == "C2":
         cpu = cpu_baseline(camera, args.cpu_seconds, all_cores=not args.no_extras)   # before torch / HIP are loaded: the workers are forks
 
     import torch
@@ -423,7 +527,12 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
-    n_local = args.envs_per_gpu
+    if args.config != "C2":
+        line = config_headline(args, torch, dist, rank, world, local, cpu)
+        if rank == 0:
+            print(json.dumps(line))
+        return
+    n_local = args.envs_per_gpu or 256
     n_total = n_local * world
     K, W = args.steps, args.warmup
 
@@ -500,9 +609,8 @@ def main():
                                   "repeats": len(t3), "note": "every env its own wind: 5-15 m/s, any direction (aoenv_set_wind_env); same camera as the headline"}
     if rank != 0:
         return
-    pmc = load_pmc(n_local, camera)
-    if roof is not None and pmc is not None:
-        roof["traffic"] = pmc.get("kernels", {}).get(roof["kernel"], {}).get("hbm_bytes_per_launch")
+    pmc = load_pmc(n_local, camera, camera)
+    attach_traffic(roof, pmc)
     fl = mfma_flops_per_env_step(env)
     out = {
         "metric": "AO env-steps/sec (batched loops)", "value": n_total * K / dt, "unit": "env-steps/s",
@@ -539,6 +647,7 @@ def main():
             if name not in CONFIGS:
                 raise SystemExit(f"unknown config {name}: choose from {sorted(CONFIGS)}")
             try:
+                args.envs_per_gpu = None
                 out["configs"][name] = bench_config(name, args, torch, timer)
             except Exception as exc:                           # a config leg must not take the headline line down with it
                 out["configs"][name] = {"error": f"{type(exc).__name__}: {exc}"}

@@ -38,6 +38,11 @@ CASES = {
     "tiny_3layer": dict(R=24, nsub=4, D=1.6, r0=0.13, L0=30.0, ws=[10.0, 12.0, 11.0], wd=[0.0, 72.0, 144.0],
                         frac=[0.45 / 0.65, 0.1 / 0.65, 0.1 / 0.65], alt=[0.0, 0.0, 0.0],
                         n_modes=8, steps=30, seeds=[17], gain=0.5, full_every=1),
+    # the reference env's own telescope has fov = 1 arcsec (MAIN/OOPAOEnv/OOPAOEnv.py:129): a layer at altitude h then lives on a grid of
+    # ceil(R / D (D + 2 tan(fov / 2) h)) + 4 pixels with ring operators of its own (OOPAO/Atmosphere.py:216-218): 28, 29, 29 here
+    "tiny_3layer_fov1": dict(R=24, nsub=4, D=1.6, r0=0.13, L0=30.0, ws=[10.0, 12.0, 11.0], wd=[0.0, 72.0, 144.0],
+                             frac=[0.45 / 0.65, 0.1 / 0.65, 0.1 / 0.65], alt=[0.0, 1000.0, 5000.0], fov=1.0,
+                             n_modes=8, steps=30, seeds=[17], gain=0.5, full_every=1),
     "small_sh": dict(R=48, nsub=8, D=3.2, r0=0.13, L0=30.0, ws=[10.0], wd=[72.0], frac=[1.0], alt=[0.0],
                      n_modes=20, steps=50, seeds=[0, 17], gain=0.5, full_every=10),
     "c2_sh": dict(R=120, nsub=20, D=8.0, r0=0.13, L0=30.0, ws=[10.0], wd=[72.0], frac=[1.0], alt=[0.0],
@@ -55,6 +60,10 @@ CASES = {
     # default (centred) mask, 50 Zernike modes as OOPAOEnv.set_params keeps (SURVEY.md 8c "R=240/40 sub Pyr single step")
     "c3_pyr": dict(R=240, nsub=40, D=8.0, r0=0.13, L0=30.0, ws=[10.0], wd=[72.0], frac=[1.0], alt=[0.0],
                    n_modes=50, steps=4, seeds=[17], gain=0.5, full_every=3, wfs="pyr", modulation=0, centering=True),
+    # the same geometry with the modulation SURVEY.md 8a A6 / 8d quote (3 lambda/D: nTheta = 20, Pyramid.py:941-985): calibration at
+    # that modulation, one measurement + closed-loop steps; every step recorded in full (88 x 88 frame, 2608 signals)
+    "c3_pyr_mod3": dict(R=240, nsub=40, D=8.0, r0=0.13, L0=30.0, ws=[10.0], wd=[72.0], frac=[1.0], alt=[0.0],
+                        n_modes=50, steps=3, seeds=[17], gain=0.5, full_every=1, wfs="pyr", modulation=3, centering=True),
     # BASELINE.json configs[4] per-env physics: 3 layers (the first three of papyrus_config.yaml's commented profile, Cn2
     # renormalised) + two chained DMs (20x20 and 10x10 pitch, the second one altitude-conjugated at 5000 m:
     # with fov = 0 it has the ground DM's grid, OOPAO/DeformableMirror.py:388-389), tel*dm1*dm2*wfs in closed loop
@@ -68,7 +77,7 @@ def build(ref, c):
     """Reference objects, composed as OOPAOEnv.set_params does (with an SH WFS)."""
     with RL.quiet():
         tel = ref.Telescope(resolution=c["R"], diameter=c["D"], samplingTime=1 / 500, centralObstruction=0,
-                            display_optical_path=False, fov=0)
+                            display_optical_path=False, fov=c.get("fov", 0))
         ngs = ref.Source(optBand="I", magnitude=8, coordinates=[0, 0])
         ngs * tel
         atm = ref.Atmosphere(telescope=tel, r0=c["r0"], L0=c["L0"], windSpeed=list(c["ws"]),
@@ -164,6 +173,17 @@ class _Coefs:
             tel * self.dm * self.dm2 * wfs                        # paired telescope: every DM adds its OPD (Telescope.py:533-544)
 
 
+def _stack_maps(atm):
+    """layer.mapShift of every layer as one array [nLayer, S, S]; layers on smaller grids (fov != 0: the grid grows with the
+    altitude) sit in the top-left corner of an S = max(S_l) frame, zero beyond (cfg_layer_S holds every S_l)."""
+    maps = [getattr(atm, f"layer_{i + 1}").mapShift for i in range(atm.nLayer)]
+    S = max(m.shape[0] for m in maps)
+    out = np.zeros((len(maps), S, S))
+    for l, m in enumerate(maps):
+        out[l, :m.shape[0], :m.shape[1]] = m
+    return out
+
+
 def run_episode(env, c, seed, dm_prev_in=None):
     """mbrl.py:49-55 prologue + integrator closed loop through OOPAOEnv.step arithmetic.  dm_prev_in: the env's dm_prev as
     the previous episode left it (the prologue's ``dm.coefs = 0`` does not clear it, OOPAOEnv.py:314, 508-509); None = a
@@ -186,7 +206,7 @@ def run_episode(env, c, seed, dm_prev_in=None):
     obs0 = vec_to_img(-np.matmul(recon, wfs.signal)) * 1e6          # reset_soft
     T = c["steps"]
     R = c["R"]
-    out = dict(obs0=obs0, mapShift0=np.stack([getattr(atm, f"layer_{i + 1}").mapShift.copy() for i in range(atm.nLayer)]),
+    out = dict(obs0=obs0, mapShift0=_stack_maps(atm),
                signal0=wfs.signal.copy(),
                actions=np.zeros((T, nAct, nAct), np.float32), obs=np.zeros((T, nAct, nAct)),
                reward=np.zeros(T), strehl=np.zeros(T), total=np.zeros(T), residual=np.zeros(T),
@@ -220,7 +240,7 @@ def run_episode(env, c, seed, dm_prev_in=None):
             out["opd_atm"].append(opd_atm)
             out["opd_res"].append(tel.OPD.copy())
             out["frame"].append(wfs.cam.frame.copy())
-            out["mapShift"].append(np.stack([getattr(atm, f"layer_{l + 1}").mapShift.copy() for l in range(atm.nLayer)]))
+            out["mapShift"].append(_stack_maps(atm))
     for k in ("opd_atm", "opd_res", "frame", "mapShift", "full_steps"):
         out[k] = np.asarray(out[k])
     assert opd_atm.shape == (R, R)
@@ -242,6 +262,11 @@ def make_case(ref, name):
         pupil=tel.pupil.astype(bool), wavelength=env["ngs"].wavelength, nPhoton=env["ngs"].nPhoton,
         validAct=np.asarray(env["dm_mask"], bool).reshape(-1),
         m2c=env["m2c"], F=env["F"], xvalid=env["xvalid"], yvalid=env["yvalid"])
+    if c.get("fov"):
+        layers = [getattr(atm, f"layer_{i + 1}") for i in range(atm.nLayer)]
+        consts.update(cfg_fov=float(c["fov"]), cfg_layer_S=np.array([l.mapShift.shape[0] for l in layers]))
+        for i, l in enumerate(layers[1:], start=1):                   # (layer 0's operators are `A`, `B` below)
+            consts.update({f"A_l{i}": l.A, f"B_l{i}": l.B})
     if dm2 is not None:
         consts.update(cfg_second_nsub=c["second_nsub"], cfg_second_alt=float(c.get("second_alt") or 0.0),
                       validAct1=np.asarray(dm.validAct, bool), validAct2=np.asarray(dm2.validAct, bool))
@@ -276,6 +301,10 @@ def make_case(ref, name):
         if dm2 is not None:
             pc2 = rs.randn(dm2.nValidAct)
             consts.update(modes2_probe_in=pc2, modes2_probe_out=dm2.modes @ pc2, modes2_fro=np.linalg.norm(dm2.modes))
+    if name == "c2_sh":
+        # the ring operators of the headline geometry in full, in a file of their own (5.9 MB): with them injected the float64 shards
+        # are compared at the same-operator tolerance (1e-12) at one FULL size (tests/test_gpu_parity.py, "f64-refAB")
+        np.savez_compressed(os.path.join(GOLD, "c2_sh_AB.npz"), A=L1.A, B=L1.B)
     out = dict(consts)
     if c["R"] > 48:
         out.pop("F")                       # derived from the m2c input alone; keep the fixture small

@@ -290,6 +290,7 @@ struct StepArgs {
     int n_modes, n_subap, n_valid, n_env;
 };
 int step_fused_supported(int R, int n_subap, int n_valid, int n_act, int n_modes);
+int step_alias_capacity(int n_act);
 int launch_env_step(const StepArgs& a, hipStream_t st);
 
 template <typename T>

@@ -198,22 +198,31 @@ __device__ inline uint32_t word_of(const uint32_t (&o)[4], int s) {
     return ov[s];
 }
 
-// The photon count of one pixel: Poisson(lam) from the alias tables (poisson_alias.hpp; `tab` = the table where this kernel keeps it,
-// LDS or global), or by PTRS at and above the table's end.  EVERY lane of a wave must call (PTRS votes across the wave).
-// wf, wr, wc: the pixel's words of the quad draws kDrawPhoton, kDrawPhoton2, kDrawPhoton3 (wc is only looked at where lam >= 32).
-__device__ inline float photon_count(float lam, uint32_t wf, uint32_t wr, uint32_t wc, uint32_t pixel, uint32_t env, const DetectorCfg& d,
-                                     float lmax, const uint32_t* __restrict__ tab) {
-    const bool over = lam >= lmax;
-    float k = poisson_alias<true>(over ? 0.f : lam, wf, wr, wc, tab);
-    if (__any(over)) {
-        const float kb = poisson_ptrs(over ? lam : kPtrsFrom, wf, wc, pixel, env, d);
-        k = over ? kb : k;
+// The photon counts of a quad: Poisson(v[s]) from the alias tables (poisson_alias.hpp; `tab` = the table where this kernel keeps it,
+// LDS or global) -- straight-line code, the same cost for every lane -- then, for pixels at and above the table's end, PTRS in ONE
+// rolled block that a wave enters only if it holds such a pixel.  EVERY lane of a wave must call (PTRS votes across the wave).
+// o, o2, o3: the quad draws kDrawPhoton, kDrawPhoton2, kDrawPhoton3 (o3 is only looked at where v[s] >= 32).
+__device__ inline void photon_quad(f32x4d& v, const uint32_t (&o)[4], const uint32_t (&o2)[4], const uint32_t (&o3)[4], const u32x4d& pix,
+                                   uint32_t env, const DetectorCfg& d, float lmax, const uint32_t* __restrict__ tab) {
+    f32x4d k;
+    bool over = false;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const bool ov = v[s] >= lmax;
+        over = over || ov;
+        k[s] = poisson_alias<true>(ov ? 0.f : v[s], o[s], o2[s], o3[s], tab);
     }
-    return k;
-}
-__device__ inline float photon_count(float lam, uint32_t wf, uint32_t wr, uint32_t wc, uint32_t pixel, uint32_t env, const DetectorCfg& d,
-                                     const PoissonAlias& pa) {
-    return photon_count(lam, wf, wr, wc, pixel, env, d, pa.lmax, pa.tab);
+    if (__any(over)) {
+        const u32x4d ov = {o[0], o[1], o[2], o[3]}, o3v = {o3[0], o3[1], o3[2], o3[3]};
+#pragma unroll 1
+        for (int s = 0; s < 4; ++s) {
+            const bool big = v[s] >= lmax;
+            if (!__any(big)) continue;
+            const float kb = poisson_ptrs(big ? v[s] : kPtrsFrom, ov[s], o3v[s], pix[s], env, d);
+            k[s] = big ? kb : k[s];
+        }
+    }
+    v = k;
 }
 
 // One quad of the camera, photons in -> counts out (used where the caller has no cheaper arrangement: k_detector, the unlit
@@ -230,7 +239,8 @@ __device__ inline void detector_quad(f32x4d& v, const uint32_t (&pix)[4], uint32
         if (__any(v[0] >= palias::kCoarseStep || v[1] >= palias::kCoarseStep || v[2] >= palias::kCoarseStep || v[3] >= palias::kCoarseStep))
             quad_bits(quad, env, d, kDrawPhoton3, o3);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) v[s] = photon_count(fmaxf(v[s], 0.f), o[s], o2[s], o3[s], pv[s], env, d, pa);
+        for (int s = 0; s < 4; ++s) v[s] = fmaxf(v[s], 0.f);
+        photon_quad(v, o, o2, o3, pv, env, d, pa.lmax, pa.tab);
     }
     f32x4d dark = {0.f, 0.f, 0.f, 0.f}, nrm = {0.f, 0.f, 0.f, 0.f};
     if (d.dark_e > 0.f) {

@@ -84,25 +84,25 @@ __global__ void __launch_bounds__(512) k_detector_sh6(float* __restrict__ frame,
         const int li = k / n_subap, lj = k - li * n_subap;
         const uint32_t px0 = (uint32_t)((li * 6) * cam + lj * 6 + q3);
         float* fr = frame + (size_t)e * cam * cam + px0;
-        f32x16s pxv;
+        float Ia[6], Ib[6];
 #pragma unroll
         for (int u = 0; u < 6; ++u) {
-            pxv[u] = live ? fr[(size_t)u * cam] : 0.f;
-            pxv[6 + u] = live ? fr[(size_t)u * cam + 3] : 0.f;
+            Ia[u] = live ? fr[(size_t)u * cam] : 0.f;
+            Ib[u] = live ? fr[(size_t)u * cam + 3] : 0.f;
         }
-#pragma unroll
-        for (int u = 12; u < 16; ++u) pxv[u] = 0.f;
+        f32x16s pxv = camera_pack(Ia, Ib);
         if (c == 0) __syncthreads();                                // vmcnt(0) + barrier: every wave's share of the table has landed
         camera_sh6_lane(pxv, live, px0, cam, (uint32_t)e, d, tab_s, pa.lmax);
+        camera_unpack(pxv, Ia, Ib);
         if (live) {
             const bool lit = valid2d[k] != 0;
 #pragma unroll
             for (int u = 0; u < 6; ++u) {
-                fr[(size_t)u * cam] = pxv[u];
-                fr[(size_t)u * cam + 3] = pxv[6 + u];
+                fr[(size_t)u * cam] = Ia[u];
+                fr[(size_t)u * cam + 3] = Ib[u];
                 if (lit) {
-                    mx = pxv[u] > mx ? pxv[u] : mx;
-                    mx = pxv[6 + u] > mx ? pxv[6 + u] : mx;
+                    mx = Ia[u] > mx ? Ia[u] : mx;
+                    mx = Ib[u] > mx ? Ib[u] : mx;
                 }
             }
         }

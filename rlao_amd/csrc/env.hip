@@ -8,6 +8,7 @@
 
 #include "common.hpp"
 #include "detector.hpp"
+#include "sh_device.hpp"
 
 namespace ao {
 
@@ -133,8 +134,9 @@ struct AoEnv {
     void* vbuf = nullptr;                   // [E][A]
     DetectorCfg det{};                      // aoenv_set_detector(); det.active = 0: ideal camera
     uint32_t* alias_tab = nullptr;          // alias tables of the photon-noise sampler (poisson_alias.hpp), whole
-    int alias_words = 0;
-    PoissonAlias alias() const { return PoissonAlias{alias_tab, alias_words, palias::kCoarseStep * palias::kMaxCoarseRows}; }
+    int alias_words = 0;                    // the part of them this env's kernels use, and the photon count it reaches: geometries
+    float alias_lmax = 0.f;                 // the fused step kernel can take keep what fits in ITS LDS, for every camera kernel
+    PoissonAlias alias() const { return PoissonAlias{alias_tab, alias_words, alias_lmax}; }
     bool det_seeded = false;                // a seed has been set: the frame counter survives later aoenv_set_detector calls
     void* ret_acc = nullptr;                // caller-owned [E] episode-return accumulator (aoenv_set_return_accumulator)
     std::vector<void*> allocs;
@@ -958,7 +960,10 @@ int aoenv_create(const AoCfg* cfg, int device, AoEnv** out) {
     A_(&e->vbuf, (size_t)kMaxSplits * E * e->A * z);
     {
         const PoissonAliasHost& ph = poisson_alias_host();
-        e->alias_words = (int)ph.tab.size();
+        int budget = (int)ph.tab.size();
+        if (cfg->wfs_type == AOENV_WFS_SH && e->p == fast6::P && e->R <= 128 && e->nAct <= 32) budget = std::min(budget, step_alias_capacity(e->nAct));
+        ph.prefix(budget, &e->alias_words, &e->alias_lmax);
+        if (e->alias_lmax < palias::kCoarseStep && !rc) rc = fail("aoenv_create: no room for the photon-noise tables");
         A_((void**)&e->alias_tab, ph.tab.size() * 4);
         if (!rc && hipMemcpy(e->alias_tab, ph.tab.data(), ph.tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
             rc = fail("aoenv_create: upload of the photon-noise tables failed");

@@ -119,9 +119,14 @@ __global__ void k_test_poisson(const float* __restrict__ lam, float* __restrict_
     quad_bits((uint32_t)(i >> 2), 0u, d, kDrawPhoton, o);
     quad_bits((uint32_t)(i >> 2), 0u, d, kDrawPhoton2, o2);
     quad_bits((uint32_t)(i >> 2), 0u, d, kDrawPhoton3, o3);
-    const float l = live ? fmaxf(lam[i], 0.f) : 0.f;
-    const float k = photon_count(l, word_of(o, i & 3), word_of(o2, i & 3), word_of(o3, i & 3), (uint32_t)i, 0u, d, pa);
-    if (live) out[i] = k;
+    // (every lane draws its whole quad and keeps its own slot: photon_quad is the code path of the cameras)
+    const int q4 = i & ~3;
+    f32x4d v;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) v[s] = (live && q4 + s < n) ? fmaxf(lam[q4 + s], 0.f) : 0.f;
+    const u32x4d pix = {(uint32_t)q4, (uint32_t)q4 + 1u, (uint32_t)q4 + 2u, (uint32_t)q4 + 3u};
+    photon_quad(v, o, o2, o3, pix, 0u, d, pa.lmax, pa.tab);
+    if (live) out[i] = v[i & 3];
 }
 
 }  // namespace ao

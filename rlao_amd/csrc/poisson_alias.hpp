@@ -57,9 +57,14 @@ void build_poisson_alias(PoissonAliasHost& out);
 const PoissonAliasHost& poisson_alias_host();   // built once per process
 
 #ifdef __HIPCC__
+#ifndef AO_ABL
+#define AO_ABL(bit) 0                                             // (timing ablations, scripts/diag_cam_ablate.sh: wrong frames)
+#endif
 // one alias draw from row `row` with the 32-bit word w
 __device__ inline uint32_t alias_draw(const uint32_t* __restrict__ tab, int row, uint32_t w) {
-    const uint2 d = *reinterpret_cast<const uint2*>(tab + palias::kHeader + 2 * row);
+    uint2 d = *reinterpret_cast<const uint2*>(tab + palias::kHeader + 2 * row);
+    if (AO_ABL(2)) d = uint2{(uint32_t)(palias::kHeader + 400 + 64 * row), 64u};
+    if (AO_ABL(3)) return (uint32_t)(((uint64_t)w * d.y) >> 32);
     const uint32_t n = d.y & 0xffffu, kmin = d.y >> 16;
     const uint64_t prod = (uint64_t)w * n;                         // v_mad_u64_u32: cell and the fraction inside it in one instruction
     const uint32_t cell = (uint32_t)(prod >> 32), frac = (uint32_t)prod;
@@ -83,7 +88,7 @@ __device__ inline float poisson_alias(float lam, uint32_t wf, uint32_t wr, uint3
     float p = __expf(-dl), cdf = p;
     const float u = u01_23(wr);
 #pragma unroll
-    for (int t = 0; t < 7; ++t) {
+    for (int t = 0; t < (AO_ABL(4) ? 1 : 7); ++t) {
         k += u > cdf ? 1u : 0u;
         p *= dl * (1.0f / (float)(t + 1));
         cdf += p;

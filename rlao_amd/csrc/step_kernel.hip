@@ -20,6 +20,12 @@
 //
 // Arithmetic is the same as in the separate kernels (phase_kernel.hip, sh_kernels.hip); only summation orders of the
 // centroid and of the telemetry differ (float32 / float64 rounding level).  No atomics: bitwise reproducible.
+// diagnostic ablation of the camera block (scripts/diag_cam_ablate.sh): -DAO_CAM_ABLATE=<bit mask>; wrong frames, timing only
+#ifdef AO_CAM_ABLATE
+#define AO_ABL(bit) (((AO_CAM_ABLATE) >> (bit)) & 1)
+#else
+#define AO_ABL(bit) 0
+#endif
 #include "common.hpp"
 
 // Diagnostic build only (-DAO_STEP_STAMPS): wave 0 of each workgroup stamps s_memtime at the stage boundaries.
@@ -36,12 +42,6 @@ namespace ao { __device__ unsigned long long g_stamps[1024 * 32]; __device__ uns
 #include "detector.hpp"
 #include "ring_device.hpp"
 
-// diagnostic ablation of the camera block (scripts/diag_cam_ablate.sh): -DAO_CAM_ABLATE=<bit mask>; wrong frames, timing only
-#ifdef AO_CAM_ABLATE
-#define AO_ABL(bit) (((AO_CAM_ABLATE) >> (bit)) & 1)
-#else
-#define AO_ABL(bit) 0
-#endif
 #include "camera_sh6.hpp"
 
 
@@ -488,18 +488,16 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
     if (a.det.active) {
         // ---- self*self.cam: the camera on the lane's 12 pixels (detector.hpp, "Stream layout") --------------------------------
         // (camera_sh6.hpp: shared with the stand-alone camera kernel)
-        f32x16s pxv;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) { pxv[i] = Ia[i]; pxv[6 + i] = Ib[i]; }
-#pragma unroll
-        for (int i = 12; i < 16; ++i) pxv[i] = 0.f;
+        f32x16s pxv = camera_pack(Ia, Ib);
+        AO_STAMP(23);
         if (cam_photons) {                                        // this wave's share of the tables has landed; then everybody's
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            AO_STAMP(6);
             lds_barrier();
         }
+        AO_STAMP(8);
         camera_sh6_lane(pxv, ok, (uint32_t)((li * 6) * R + lj * 6 + q3), R, (uint32_t)e, a.det, tab_s, a.pa.lmax);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) { Ia[i] = pxv[i]; Ib[i] = pxv[6 + i]; }
+        camera_unpack(pxv, Ia, Ib);
     }
     if (ok) {
         float* fr = a.frame + pix0 + (size_t)(li * 6) * R + lj * 6 + q3;
@@ -694,14 +692,14 @@ int step_fused_supported(int R, int n_subap, int n_valid, int n_act, int n_modes
     return (size_t)L.total * 4 <= 160 * 1024 - 1024 ? 1 : 0;     // static __shared__ of the kernel: < 1 KB
 }
 
-int launch_env_step(const StepArgs& a_in, hipStream_t st) {
-    StepArgs a = a_in;
+// words of LDS the fused kernel has for the camera's alias tables (where stage A's buffers were): the env keeps the part of the
+// tables that fits there for ALL its camera kernels, so that a pixel is drawn the same way whichever kernel meets it
+int step_alias_capacity(int n_act) { return step_lds_layout(n_act, 1, 1, 1).tab_cap; }
+
+int launch_env_step(const StepArgs& a, hipStream_t st) {
     const StepLds L = step_lds_layout(a.k.n_act, a.n_subap, a.n_valid, a.n_modes);
-    if (a.det.active && a.det.photon_noise) {                     // as much of the alias tables as fits where stage A's buffers were
-        if (!a.pa.tab) return fail("fused step: the photon-noise tables are missing");
-        poisson_alias_host().prefix(std::min(L.tab_cap, a.pa.words), &a.pa.words, &a.pa.lmax);
-        if (a.pa.lmax < palias::kCoarseStep) return fail("fused step: no room for the photon-noise tables (%d words)", L.tab_cap);
-    }
+    if (a.det.active && a.det.photon_noise && (!a.pa.tab || a.pa.words > L.tab_cap || a.pa.lmax < palias::kCoarseStep))
+        return fail("fused step: the photon-noise tables are missing or do not fit (%d words, room for %d)", a.pa.words, L.tab_cap);
     const size_t lds = (size_t)L.total * 4;
     const int v = a.k.n_act <= 24 ? 0 : 1;
     const bool pe = a.k.pa.env_taps != nullptr;

@@ -5,7 +5,7 @@
 #   tracked profiles/<tag>_kernel_stats.csv and profiles/<tag>_pmc.json.
 #   usage: scripts/pmc_collect.sh TAG [bench flags...]
 set -o pipefail
-TAG=${1:-r02}; shift
+TAG=${1:-r03}; shift
 BENCH="bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --min-seconds 0.2 $*"
 OUT=$PWD/gpurun_out
 cd /tmp && export TMPDIR=/tmp

@@ -5,9 +5,9 @@ OUT=$PWD/gpurun_out
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 for C in "$@"; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/r02_${C}_trace -- python3 $REPO/scripts/prof_config.py $C > $OUT/r02_${C}_trace.log 2>&1 || echo "trace $C failed"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/r03_${C}_trace -- python3 $REPO/scripts/prof_config.py $C > $OUT/r03_${C}_trace.log 2>&1 || echo "trace $C failed"
   for P in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $P --output-format csv -d $OUT/r02_${C}_pmc_$P -- python3 $REPO/scripts/prof_config.py $C > $OUT/r02_${C}_pmc_$P.log 2>&1 || echo "pmc $P $C failed"
+    rocprofv3 --pmc $P --output-format csv -d $OUT/r03_${C}_pmc_$P -- python3 $REPO/scripts/prof_config.py $C > $OUT/r03_${C}_pmc_$P.log 2>&1 || echo "pmc $P $C failed"
   done
 done
 echo done

@@ -201,8 +201,15 @@ def test_c4_elt_closed_loop_matches_oracle():
     geom = O.LayerGeometry(R, 39.0, 30.0)
     AB = geom.AB(0.13)                                           # the ring operators handed to both sides (host pinv differs at 1e-9)
     base, worst = None, {}
-    for dtype, tol in (("f64", dict(obs=2e-7, sig=1e-9, res=1e-6, sr=1e-9, rew=1e-9)),
-                       ("f32", dict(obs=2e-3, sig=2e-3, res=2e-2, sr=2e-5, rew=2e-4))):
+    # float32: the centre of gravity keeps the pixels above 1 % of the brightest pixel of the whole frame (ShackHartmann.py:316): a pixel
+    # within float32 rounding of that threshold flips in or out, and the slope of a dim lenslet jumps (measured: a handful of
+    # the 10048 slopes per step, up to ~1 slope unit).  The slopes are therefore compared by the FRACTION beyond the tolerance; the
+    # observation (R s over all slopes) carries a flip at the 1e-3 um level.
+    # Tolerances ~10x the maxima measured on MI355X (round 3, AO_PARITY_REPORT): float64 obs 5.1e-14 um, slopes 4.4e-12, rms 5.7e-13 nm,
+    # reward 3.2e-14; float32 obs 3.2e-4 um, slopes 1.7e-4 (99.8 % quantile; 2 of 10048 beyond 2e-3: threshold flips, largest 2.2),
+    # rms 2.2e-4 nm, reward 4.6e-5, commands 2.1e-13 m.
+    for dtype, tol in (("f64", dict(obs=5e-13, sig=5e-11, res=1e-11, sr=1e-15, rew=1e-12, flips=0.0)),
+                       ("f32", dict(obs=3e-3, sig=2e-3, res=3e-3, sr=2e-5, rew=5e-4, flips=2e-3))):
         env = BatchedAOEnv(n_envs=2, device=0, dtype=dtype)
         try:
             env.set_params(C4, camera="ideal", wfs_type="shackhartmann", atm_AB=AB)
@@ -233,12 +240,20 @@ def test_c4_elt_closed_loop_matches_oracle():
                 sig = env.wfs.signal
                 for k, o in enumerate(orcs):
                     oo, of, orw, osr, _, _ = o.step(i, act[k].double().cpu().numpy())
-                    d = dict(obs=np.abs(obs[k].cpu().numpy() - oo).max(), sig=np.abs(sig[k] - o.wfs.signal).max(),
-                             sr=abs(float(sr[k]) - osr), rew=abs(float(rew[k]) - orw) / abs(orw))
+                    ds = np.abs(sig[k] - o.wfs.signal)
+                    d = dict(obs=np.abs(obs[k].cpu().numpy() - oo).max(), sig=np.sort(ds)[int((1 - tol["flips"]) * (ds.size - 1))],
+                             flips=float((ds > tol["sig"]).mean()), sig_max=ds.max(), sr=abs(float(sr[k]) - osr),
+                             rew=abs(float(rew[k]) - orw) / abs(orw))
                     for q, v in d.items():
                         worst[(dtype, q)] = max(worst.get((dtype, q), 0.0), float(v))
-                        assert v <= tol[q], (dtype, q, i, k, v)
+                        assert q == "sig_max" or v <= tol[q], (dtype, q, i, k, v)
                     np.testing.assert_allclose(frame[k].cpu().numpy(), of, atol=(1e-9 if dtype == "f64" else 5e-5) * of.max())
+                if dtype == "f32":                                # the oracles follow the env's own trajectory: a flipped slope of one step
+                    for k, o in enumerate(orcs):                  # does not compound through the integrator into the next comparison
+                        worst[(dtype, "coefs")] = max(worst.get((dtype, "coefs"), 0.0), float(np.abs(env.dm.coefs[k] - o.coefs).max()))
+                        np.testing.assert_allclose(env.dm.coefs[k], o.coefs, atol=2e-9)       # (0.5 x obs tolerance, in metres)
+                        o.coefs = env.dm.coefs[k].astype(np.float64)
+                        o.dm_prev = o.coefs.copy()
             assert crossed
             res, tot = env.residual[:steps], env.total[:steps]
             for k, o in enumerate(orcs):

@@ -173,6 +173,15 @@ def test_bench_spawns_its_ranks_for_gpus_n():
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
     tail = cmd[cmd.index(os.path.join(REPO, "bench.py")) + 1:]
     assert tail == ["--gpus", "4", "--steps", "20", "--warmup", "5"]
+    # BASELINE configs[3] / configs[4] as they are stated: `--gpus 8 --config C4|C5` goes to the ranks unchanged
+    for cfg in ("C4", "C5"):
+        out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8", "--config", cfg, "--dry-run-launch"],
+                             capture_output=True, text=True, env=env, timeout=120)
+        assert out.returncode == 0, out.stderr
+        cmd = json.loads(out.stdout.strip().splitlines()[-1])["launch"]
+        assert "--nproc-per-node=8" in cmd and cmd[cmd.index("--config") + 1] == cfg
+    import bench
+    assert bench.CONFIGS["C4"]["envs"] * 8 == 4096 and bench.CONFIGS["C5"]["envs"] * 8 == 2048      # BASELINE.json configs[3], [4]
     # inside a rank environment nothing is spawned: the same flags fall through to the benchmark itself
     import bench
     args = type("A", (), {"gpus": 4, "dry_run_launch": False})()

@@ -105,12 +105,15 @@ def test_closed_loop_replay(case):
                 assert done is False
 
 
-def test_c3_pyramid_full_size(golden_dir):
-    """BASELINE configs[2] at its real size (8 m, 40x40 Pyramid, R = 240, nRes = 528 = 16 * 3 * 11, 1353 actuators): the oracle
+@pytest.mark.parametrize("fixture", ["c3_pyr", "c3_pyr_mod3"])
+def test_c3_pyramid_full_size(golden_dir, fixture):
+    """(c3_pyr_mod3: the same with modulation 3 lambda/D, nTheta = 20 -- OOPAO/Pyramid.py:589-598, 941-985.)
+    BASELINE configs[2] at its real size (8 m, 40x40 Pyramid, R = 240, nRes = 528 = 16 * 3 * 11, 1353 actuators): the oracle
     against the reference's Pyramid / Atmosphere / DeformableMirror.  The 1353-poke interaction matrix is pinned through three
     whole columns; the modal command matrix calib.M is then taken from the fixture (pinv of a 2608 x 50 matrix: checked too)."""
-    g = np.load(os.path.join(golden_dir, "c3_pyr.npz"))
+    g = np.load(os.path.join(golden_dir, fixture + ".npz"))
     env = _env_from_golden(g, modal_cm=g["modal_cm"])
+    assert env.wfs.nTheta == (20 if fixture.endswith("mod3") else 1)
     assert env.R == 240 and env.wfs.nRes == 528 and env.nValidAct == 1353 and env.wfs.nSignal == 2608
     assert np.array_equal(env.pupil, g["pupil"]) and np.array_equal(env.dm_mask.reshape(-1), g["validAct"])
     assert np.array_equal(env.wfs.validI4Q, g["validI4Q"]) and env.wfs.nTheta == int(g["nTheta"])
