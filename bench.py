@@ -429,6 +429,7 @@ def bench_config(name, args, torch, timer, rank=0, world=1):
         obs = start_episode(env)
         env.run_integrator(0, 2 * K)
         out["integrator_mean_strehl"] = float(env._strehl.mean())
+        out["integrator_residual_over_total_rms"] = float(env.residual[2 * K - 1].mean() / env.total[2 * K - 1].mean())
     else:
         env.run_integrator(0, 4)
         env.accumulate_returns(returns)
@@ -440,6 +441,8 @@ def bench_config(name, args, torch, timer, rank=0, world=1):
         times = timer.regions(region, args.min_seconds, min_repeats=3, max_repeats=500)
         env.accumulate_returns(None)
         out["controller"] = "leaky integrator, gain 0.5, on the device"
+        last = 8 + ((len(times) - 1) % 8) * K + K - 1
+        out["residual_over_total_rms"] = float(env.residual[last].mean() / env.total[last].mean())
         prof_run = lambda: env.run_integrator(8 + 9 * K, K)     # noqa: E731
         out["mean_strehl"] = float(env._strehl.mean())
     s = stats(times)
@@ -479,7 +482,7 @@ def config_headline(args, torch, dist, rank, world, local, cpu):
                        "parallelism": f"env-shards x{world}, all-gather of episode returns"},
             "roofline": roof, "step_roofline": r["step_roofline"], "mfma": r["mfma"], "kernels": r["kernels"],
             "mean_strehl_last_step": r["mean_strehl"], "mean_episode_return": r["mean_episode_return"]}
-    for k in ("region_ms_per_rank", "integrator_mean_strehl", "policy_ms_per_step", "traffic_vs_algorithmic"):
+    for k in ("region_ms_per_rank", "integrator_mean_strehl", "integrator_residual_over_total_rms", "residual_over_total_rms", "policy_ms_per_step"):
         if k in r:
             line[k] = r[k]
     if cpu is not None:

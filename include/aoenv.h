@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define AOENV_ABI_VERSION 5
+#define AOENV_ABI_VERSION 6
 
 enum { AOENV_F32 = 0, AOENV_F64 = 1 };
 enum { AOENV_WFS_SH = 0, AOENV_WFS_PYRAMID = 1 };
@@ -64,6 +64,11 @@ typedef struct AoCfg {
     int32_t pyr_norm_valid;  /* Pyramid: 0 = 'slopesMaps_incidence_flux' (norm = frame.mean()), 1 = 'slopesMaps' */
     int32_t pyr_q_lo;        /* Pyramid: first row/column of quadrants 1 (and of the low side of 2, 4) in the frame */
     int32_t pyr_q_hi;        /* Pyramid: first row/column of the high-side quadrants (grabQuadrant, OOPAO/Pyramid.py:774-790) */
+    int32_t layer_res_l[8];  /* per-layer N: 0 = layer_res.  With a field of view (the reference env builds its telescope with
+                                fov = 1 arcsec, MAIN/OOPAOEnv/OOPAOEnv.py:129) a layer at altitude h lives on a grid of
+                                N_l = ceil(R / D (D + 2 tan(fov / 2) h)) + 4 pixels with ring operators of its own
+                                (OOPAO/Atmosphere.py:216-218, 277-286); its n_inner / n_outer are 8 N_l - 16 / 4 N_l + 4.  Layers on
+                                different grids run the batched kernels (the fused step kernel needs one grid) */
     double  atm_wavelength;  /* 500e-9: wavelength the screens are expressed at (OOPAO/Atmosphere.py:134) */
     double  src_wavelength;  /* guide-star wavelength (OOPAO/Source.py:102) */
     double  leak;            /* leaky-integrator factor (MAIN/OOPAOEnv/OOPAOEnv.py:69) */
@@ -99,7 +104,7 @@ enum AoConst {
  * environment state of SURVEY.md section 5 "checkpoint / resume" plus the stage boundaries the parity
  * tests compare.  Shapes are per shard, leading dimension n_env unless noted. */
 enum AoBuf {
-    AOENV_B_SCREEN = 0,      /* [n_layer][n_env][(N+2)^2]  layer.mapShift (download only: stored as a torus)   */
+    AOENV_B_SCREEN = 0,      /* [n_layer][n_env][(N_l+2)^2]  layer.mapShift, layer after layer (stored as a torus: no flat device image) */
     AOENV_B_OPD_ATM,         /* [n_env][R*R]   atm.OPD_no_pupil                                          */
     AOENV_B_COEFS,           /* [n_env][A]     dm.coefs                                                  */
     AOENV_B_PHASE,           /* [n_env][R*R]   tel.src.phase (residual, pupil-masked, rad @ src)          */
@@ -134,6 +139,11 @@ int aoenv_destroy(AoEnv* env);
  * r0 setter re-uploads [A|B], OOPAO/Atmosphere.py:792-807). */
 int aoenv_upload(AoEnv* env, int kind, const void* h_data, size_t bytes);
 
+/* The ring tables AOENV_C_AB / AOENV_C_INNER_IDX / AOENV_C_OUTER_IDX of ONE layer, sized by that layer's grid (AoCfg.layer_res_l):
+ * layer.A / layer.B and the masks of OOPAO/Atmosphere.py:262-286.  aoenv_upload() with these kinds serves every layer at once and
+ * is only accepted when all layers share one grid. */
+int aoenv_upload_layer(AoEnv* env, int kind, int layer, const void* h_data, size_t bytes);
+
 /* Replaces: the windSpeed / windDirection setters (OOPAO/Atmosphere.py:829-873): per layer
  * ratio = (vX, vY) * samplingTime / pixel_size in pixels per frame (OOPAO/Atmosphere.py:362-363).
  * h_ratio is [n_layer][2] float64, shared by all envs of the shard.  `reset_buff` != 0 also clears the
@@ -154,7 +164,8 @@ int aoenv_set_clock_env(AoEnv* env, const double* h_clock);
 
 /* Replaces: atm.generateNewPhaseScreen(seed) (OOPAO/Atmosphere.py:560-592) for every env of the shard.
  *   h_screens [n_env][n_layer][N*N] float64: the new layer.phase screens (rad @ 500 nm), or NULL to keep
- *             the current interior;
+ *             the current interior (not with per-env clocks).  Layers on grids of their own (layer_res_l): layer-major
+ *             blocks, layer l = [n_env][N_l*N_l];
  *   h_ring_seeds [n_env][n_layer] uint32: seeds of the per-layer ring RandomState (seed + 1000*layer);
  * seeds every MT19937 stream, draws the first ring X = A.Z + B.xi on the device, rebuilds mapShift,
  * clears the sub-pixel accumulators and refreshes atm.OPD (fill_phase_support + set_OPD). */

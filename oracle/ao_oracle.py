@@ -764,14 +764,15 @@ class OracleEnv:
                  r0=0.13, L0=30.0, windSpeed=(10.0,), windDirection=(72.0,), fractionalR0=(1.0,),
                  altitude=(0.0,), mech_coupling=0.35, m2c=None, n_modes=50, light_ratio=None,
                  threshold_cog=0.01, nLoop=10000, leak=0.99, gainCL=0.5, n_meas=6, wfs_type="sh", modulation=0.0,
-                 psf_centering=True, second_dm_nsub=None, modal_cm=None, dm_dense=True, geom_AB=None):
+                 psf_centering=True, second_dm_nsub=None, modal_cm=None, dm_dense=True, geom_AB=None, fov_arcsec=0.0):
         self.R, self.D, self.dt = resolution, diameter, dt
         self.leak, self.gainCL = leak, gainCL
         self.pupil = make_pupil(resolution)
         self.wavelength, self.nPhoton = source_photometry(band, magnitude)
         self.flux_map = self.pupil.astype(float) * self.nPhoton * dt * (diameter / resolution) ** 2
         self.atm = OracleAtmosphere(resolution, diameter, dt, self.pupil, r0, L0, windSpeed, fractionalR0,
-                                    windDirection, altitude, geom_AB=geom_AB)
+                                    windDirection, altitude, geom_AB=geom_AB,
+                                    fov_rad=fov_arcsec / 206265.0)    # tel.fov_rad = fov / 206265 (OOPAO/Telescope.py)
         self.nActuator = n_subap + 1
         # dm_dense = False (ELT size: dm.modes would be 9.6 GB): the DM surface through the separable factors,
         # OPD = gy C gx^T with C the command image -- equal to modes @ coefs to rounding (tests/test_oracle_golden.py)

@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AOENV_LIB") or os.path.join(_HERE, "csrc", "libaoenv.so")   # AOENV_LIB: A/B kernel builds
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 F32, F64 = 0, 1
 WFS_SH, WFS_PYRAMID = 0, 1
 
@@ -30,7 +30,8 @@ class AoCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "abi_version", "dtype", "n_env", "resolution", "n_layer", "layer_res", "n_inner", "n_outer", "n_act",
         "n_valid_act", "dm_separable", "wfs_type", "n_subap", "n_valid_subap", "n_signal", "cam_res", "n_loop",
-        "max_group", "pyr_n_res", "pyr_n_theta", "pyr_centering", "pyr_norm_valid", "pyr_q_lo", "pyr_q_hi")] + [(n, C.c_double) for n in (
+        "max_group", "pyr_n_res", "pyr_n_theta", "pyr_centering", "pyr_norm_valid", "pyr_q_lo", "pyr_q_hi")] + [
+            ("layer_res_l", C.c_int32 * 8)] + [(n, C.c_double) for n in (
             "atm_wavelength", "src_wavelength", "leak", "threshold_cog")]
 
 
@@ -47,6 +48,7 @@ EXPORTS = {
     "aoenv_create": (C.c_int, [C.POINTER(AoCfg), C.c_int, C.POINTER(C.c_void_p)]),
     "aoenv_destroy": (C.c_int, [C.c_void_p]),
     "aoenv_upload": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
+    "aoenv_upload_layer": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
     "aoenv_set_wind": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "aoenv_new_screens": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "aoenv_new_screens_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double,

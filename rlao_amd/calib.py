@@ -101,8 +101,6 @@ def params_from_args(args=None, **overrides) -> AOParams:
     n = p.nLayer
     if not (len(p.windSpeed) == len(p.windDirection) == len(p.altitude) == n):
         raise ValueError("fractionalR0, windSpeed, windDirection and altitude must have one entry per layer")
-    if any(a != 0 for a in p.altitude) and p.fov != 0:
-        raise NotImplementedError("layers above the ground with a non-zero field of view are out of scope (SURVEY 8a A9)")
     return p
 
 
@@ -143,17 +141,14 @@ def _vk_covariance(za: np.ndarray, zb: np.ndarray, L0: float) -> np.ndarray:
     return out
 
 
-class AtmosphereTables:
-    """Geometry shared by every layer when fov = 0 (OOPAO/Atmosphere.py:192-298)."""
+class LayerTables:
+    """Ring geometry and operators of ONE layer grid of N x N pixels (OOPAO/Atmosphere.py:216-298)."""
 
-    def __init__(self, p: AOParams):
-        R, D = p.resolution, p.diameter
-        if p.fov != 0:
-            raise NotImplementedError("fov != 0")
-        self.N = N = R + 4
+    def __init__(self, N: int, R: int, D: float, L0: float):
+        self.N = N
         self.S = S = N + 2
-        self.layer_D = N * D / R
-        self.ps_loop = self.layer_D / N                        # :351
+        self.layer_D = N * D / R                               # :219
+        self.L0 = L0
         ring = np.zeros((S, S), bool)
         ring[0, :] = ring[-1, :] = ring[:, 0] = ring[:, -1] = True
         inner = ~ring
@@ -166,12 +161,11 @@ class AtmosphereTables:
         u, v = np.meshgrid(axis, axis)
         zin = (u + 1j * v)[inner]
         zout = (u + 1j * v)[ring]
-        self._zz = _vk_covariance(zin, zin, p.L0)
-        self._zx = _vk_covariance(zin, zout, p.L0)
-        self._xx = _vk_covariance(zout, zout, p.L0)
+        self._zz = _vk_covariance(zin, zin, L0)
+        self._zx = _vk_covariance(zin, zout, L0)
+        self._xx = _vk_covariance(zout, zout, L0)
         self._zz_inv = np.linalg.pinv(self._zz)
-        self.weights = np.sqrt(np.asarray(p.fractionalR0, float))
-        self.set_r0(p.r0)
+        self.foot = N // 2 - R // 2                             # first row / column of the on-axis R x R footprint (:226-232)
 
     def set_r0(self, r0: float):
         """A = ZXt^T ZZt^-1, B = chol(XXt - A ZXt) at the requested r0 (:284-286, :554-557)."""
@@ -179,6 +173,44 @@ class AtmosphereTables:
         self.A = np.matmul((self._zx * s).T, self._zz_inv / s)
         self.B = np.linalg.cholesky(self._xx * s - np.matmul(self.A, self._zx * s))
         self.AB = np.ascontiguousarray(np.concatenate([self.A, self.B], axis=1))
+
+
+class AtmosphereTables:
+    """The layers' grids and ring operators (OOPAO/Atmosphere.py:192-298).  With fov = 0, or with every layer on the ground, all
+    layers share the (R + 4)^2 grid; with a field of view (the reference env's telescope: fov = 1 arcsec, MAIN/OOPAOEnv/OOPAOEnv.py:129)
+    a layer at altitude h has ceil(R / D (D + 2 tan(fov / 2) h)) + 4 pixels across and operators of its own (:216-218).  ``layers[l]``
+    are the tables of layer l; the attributes N, S, A, B, AB, inner_idx ... are those of layer 0 (every layer's when ``uniform``)."""
+
+    def __init__(self, p: AOParams):
+        R, D = p.resolution, p.diameter
+        fov_rad = float(p.fov) / 206265.0                       # arcsec -> rad as OOPAO/Telescope.py does
+        grids = {}
+        self.layers = []
+        for h in p.altitude:
+            d_fov = D + 2 * np.tan(fov_rad / 2) * h
+            N = int(np.ceil((R / D) * d_fov)) + 4
+            if N not in grids:
+                grids[N] = LayerTables(N, R, D, p.L0)
+            self.layers.append(grids[N])
+        if not self.layers:
+            self.layers = [LayerTables(R + 4, R, D, p.L0)]
+        self._grids = list(grids.values()) or self.layers
+        self.uniform = len({t.N for t in self.layers}) == 1
+        self.layer_res = [t.N for t in self.layers]
+        g0 = self.layers[0]
+        self.N, self.S, self.layer_D = g0.N, g0.S, g0.layer_D
+        self.ps_loop = g0.layer_D / g0.N                        # :351 (the pixel size D / R, the same for every layer)
+        self.outer_mask, self.inner_mask = g0.outer_mask, g0.inner_mask
+        self.outer_idx, self.inner_idx = g0.outer_idx, g0.inner_idx
+        self.n_outer, self.n_inner = g0.n_outer, g0.n_inner
+        self.weights = np.sqrt(np.asarray(p.fractionalR0, float))
+        self.set_r0(p.r0)
+
+    def set_r0(self, r0: float):
+        for t in self._grids:
+            t.set_r0(r0)
+        g0 = self.layers[0]
+        self.A, self.B, self.AB = g0.A, g0.B, g0.AB
 
     def wind_ratio(self, speeds, directions, dt):
         """pixels per frame along (x, y) for each layer (:209-210, :352-363)."""

@@ -94,8 +94,10 @@ struct PhaseArgs {
     const void* minmax[kMaxLayer];   // [n_env][2] min / max of each mapShift (warp output clip)
     LayerTaps taps[kMaxLayer];
     int n_layer;
-    int S;                           // N + 2
-    int foot;                        // offset of the R x R pupil footprint inside the (N+2)^2 screen
+    int S;                           // N + 2 of layer 0 (the fused step kernel: every layer on that grid)
+    int foot;                        // offset of the R x R pupil footprint inside the (N+2)^2 screen, layer 0
+    int S_l[kMaxLayer];              // ... of every layer: with fov != 0 a layer at altitude h has a grid of its own
+    int foot_l[kMaxLayer];           //     (OOPAO/Atmosphere.py:216-232)
     int update_atm;                  // 1: atmosphere OPD from the screens; 0: from the opd_atm buffer (user-defined OPD)
     int store_atm;                   // 1: also write atm.OPD_no_pupil to the opd_atm buffer (state inspection)
     int store_phase;                 // 0: leave the residual phase, the telemetry sums and wfs_max untouched

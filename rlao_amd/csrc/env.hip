@@ -39,6 +39,17 @@ struct AoEnv {
     size_t esz = 4;
     int R = 0, N = 0, S = 0, A = 0, nAct = 0, E = 0, L = 0, nin = 0, nout = 0, K = 0, nSig = 0, nSub = 0, nVal = 0;
     int p = 0, n = 0, n_pupil = 0;
+    // per-layer screen grids (fov != 0: a layer at altitude h lives on a grid of its own, OOPAO/Atmosphere.py:216-218); N, S, nin,
+    // nout, K above are layer 0's (every layer's when `uniform`: the only case the fused step kernel takes)
+    int Nl[kMaxLayer] = {0}, Sl[kMaxLayer] = {0}, ninl[kMaxLayer] = {0}, noutl[kMaxLayer] = {0}, Kl[kMaxLayer] = {0};
+    size_t scr_off[kMaxLayer + 1] = {0};     // element offset of layer l's [E][S_l^2] block in `screen`
+    int Kmax = 0, noutmax = 0, Smax = 0;
+    bool uniform = true;
+    void* ab_l[kMaxLayer] = {nullptr};       // [nout_l][K_l] ring operators [A | B] of layer l
+    int* inner_idx_l[kMaxLayer] = {nullptr};
+    int* outer_idx_l[kMaxLayer] = {nullptr};
+    bool have_ab[kMaxLayer] = {false}, have_in[kMaxLayer] = {false}, have_out[kMaxLayer] = {false};
+    int last_zx_layer = 0;
     LayerClock clk[kMaxLayer];
     int org[kMaxLayer][2] = {{0, 0}};        // torus origin (oy, ox) of every layer: logical (r, c) at ((r + oy) % S, (c + ox) % S)
     int ring_pending[kMaxLayer] = {0};       // > 0: split count of a ring extrusion whose scatter the next fused step kernel will do
@@ -76,8 +87,8 @@ struct AoEnv {
     bool use_lookahead = true;              // aoenv_set_option(AOENV_OPT_RING_LOOKAHEAD): the ring pipeline
     void* zx = nullptr;                     // [E][K]  [Z | xi]
     void* xbuf = nullptr;                   // [splits][E][nout] split-K slabs of the ring GEMM
-    void* ab = nullptr;                     // [nout][K]
-    int* inner_idx = nullptr;
+    void* ab = nullptr;                     // = ab_l[0] (fused path)
+    int* inner_idx = nullptr;               // = inner_idx_l[0]
     int* outer_idx = nullptr;
     double layer_weight[kMaxLayer] = {0};
     void* gx = nullptr;
@@ -155,11 +166,11 @@ struct AoEnv {
 
     template <typename T> T* as(void* p_) const { return static_cast<T*>(p_); }
     void* screen_ptr(int which, int l) const {
-        return static_cast<char*>(screen[which]) + (size_t)l * E * S * S * esz;
+        return static_cast<char*>(screen[which]) + scr_off[l] * esz;
     }
     void* minmax_ptr(int l) const { return static_cast<char*>(minmax) + (size_t)l * E * 2 * esz; }
-    void* xbuf_ptr(int l) const { return static_cast<char*>(xbuf) + (size_t)l * kMaxSplits * E * nout * esz; }
-    void* zx_pipe_ptr(int buf, int l) const { return static_cast<char*>(zx_pipe) + ((size_t)buf * L + l) * E * K * esz; }
+    void* xbuf_ptr(int l) const { return static_cast<char*>(xbuf) + (size_t)l * kMaxSplits * E * noutmax * esz; }
+    void* zx_pipe_ptr(int buf, int l) const { return static_cast<char*>(zx_pipe) + ((size_t)buf * L + l) * E * Kmax * esz; }
 };
 
 namespace {
@@ -278,8 +289,8 @@ int flush_ring(AoEnv* env, int l, hipStream_t st) {
     // (per-env clocks: only the envs that crossed, each through its own origin, and their range right away -- there is no
     //  per-env "dirty" flag on the host)
     const LayerTaps* et = env->per_env_wind ? env->env_taps + (size_t)l * env->E : nullptr;
-    AO_TRY(launch_scatter_minmax<T>(env->as<T>(env->screen_ptr(0, l)), static_cast<const T*>(env->ring_src[l]), env->outer_idx,
-                                    env->as<T>(env->minmax_ptr(l)), env->E, env->S, env->nout, env->ring_pending[l],
+    AO_TRY(launch_scatter_minmax<T>(env->as<T>(env->screen_ptr(0, l)), static_cast<const T*>(env->ring_src[l]), env->outer_idx_l[l],
+                                    env->as<T>(env->minmax_ptr(l)), env->E, env->Sl[l], env->noutl[l], env->ring_pending[l],
                                     env->org[l][0], env->org[l][1], et ? 1 : 0, st, et));
     env->ring_pending[l] = 0;
     return 0;
@@ -299,30 +310,31 @@ int extrude(AoEnv* env, int l, int sx, int sy, bool lean, hipStream_t st, bool d
     AO_TRY(flush_ring<T>(env, l, st));                             // an earlier extrusion of this layer in the same step
     T* map = env->as<T>(env->screen_ptr(0, l));
     T* zx = env->as<T>(env->zx);
-    const int S = env->S;
+    const int S = env->Sl[l];
     const int oy = env->org[l][0], ox = env->org[l][1];
     {
         AO_PROF(env, SHIFT_GATHER, st);                           // Z gather + xi draw, one launch
-        AO_TRY(launch_ring_prepare<T>(map, zx, env->inner_idx, env->mt_cur[l], env->pos_cur[l], env->mt_cur[l], env->pos_cur[l], env->E, S,
-                                      env->nin, env->nout, env->K, sx, sy, oy, ox, st));
+        AO_TRY(launch_ring_prepare<T>(map, zx, env->inner_idx_l[l], env->mt_cur[l], env->pos_cur[l], env->mt_cur[l], env->pos_cur[l], env->E, S,
+                                      env->ninl[l], env->noutl[l], env->Kl[l], sx, sy, oy, ox, st));
     }
     int splits = 1;
     {
         AO_PROF(env, GEMM_RING, st);
-        AO_TRY(gemm_dispatch<T>(env, zx, env->as<T>(env->ab), env->as<T>(env->xbuf_ptr(l)), env->E, env->nout, env->K, &splits,
+        AO_TRY(gemm_dispatch<T>(env, zx, env->as<T>(env->ab_l[l]), env->as<T>(env->xbuf_ptr(l)), env->E, env->noutl[l], env->Kl[l], &splits,
                                 st));
     }
     // the shift itself: move the origin of the torus
     env->org[l][0] = ((oy - sy) % S + S) % S;
     env->org[l][1] = ((ox - sx) % S + S) % S;
     env->last_zx = zx;
+    env->last_zx_layer = l;
     if (defer && lean) {
         env->ring_pending[l] = splits;
         env->ring_src[l] = env->xbuf_ptr(l);
     } else {
         AO_PROF(env, SCATTER, st);
-        AO_TRY(launch_scatter_minmax<T>(map, env->as<T>(env->xbuf_ptr(l)), env->outer_idx, env->as<T>(env->minmax_ptr(l)), env->E, S,
-                                        env->nout, splits, env->org[l][0], env->org[l][1], lean ? 0 : 1, st));
+        AO_TRY(launch_scatter_minmax<T>(map, env->as<T>(env->xbuf_ptr(l)), env->outer_idx_l[l], env->as<T>(env->minmax_ptr(l)), env->E, S,
+                                        env->noutl[l], splits, env->org[l][0], env->org[l][1], lean ? 0 : 1, st));
     }
     env->minmax_dirty[l] = lean;
     return 0;
@@ -334,7 +346,7 @@ int refresh_minmax(AoEnv* env, hipStream_t st) {
     AO_TRY(flush_rings<T>(env, st));
     for (int l = 0; l < env->L; ++l)
         if (env->minmax_dirty[l]) {
-            AO_TRY(launch_minmax<T>(env->as<T>(env->screen_ptr(0, l)), env->as<T>(env->minmax_ptr(l)), env->E, env->S, st));
+            AO_TRY(launch_minmax<T>(env->as<T>(env->screen_ptr(0, l)), env->as<T>(env->minmax_ptr(l)), env->E, env->Sl[l], st));
             env->minmax_dirty[l] = false;
         }
     return 0;
@@ -364,7 +376,7 @@ bool next_crossing(const LayerClock& k0, int* sx, int* sy) {
 // The ring itself is left to that kernel (deferred scatter).  Bit-identical to extrude(): the same Z, the same xi, the same product.
 int extrude_pipelined(AoEnv* env, int l, int sx, int sy, hipStream_t st) {
     AoEnv::RingAhead& ah = env->ahead[l];
-    const int S = env->S, oy = env->org[l][0], ox = env->org[l][1];
+    const int S = env->Sl[l], oy = env->org[l][0], ox = env->org[l][1];
     const int cur = ah.buf;
     float* op = static_cast<float*>(env->zx_pipe_ptr(cur, l));
     if (ah.valid && ah.sx == sx && ah.sy == sy) {
@@ -372,20 +384,21 @@ int extrude_pipelined(AoEnv* env, int l, int sx, int sy, hipStream_t st) {
         std::swap(env->pos_cur[l], env->pos_alt[l]);
     } else {
         AO_PROF(env, SHIFT_GATHER, st);
-        AO_TRY(launch_ring_prepare<float>(env->as<float>(env->screen_ptr(0, l)), op, env->inner_idx, env->mt_cur[l], env->pos_cur[l],
-                                          env->mt_cur[l], env->pos_cur[l], env->E, S, env->nin, env->nout, env->K, sx, sy, oy, ox, st));
+        AO_TRY(launch_ring_prepare<float>(env->as<float>(env->screen_ptr(0, l)), op, env->inner_idx_l[l], env->mt_cur[l], env->pos_cur[l],
+                                          env->mt_cur[l], env->pos_cur[l], env->E, S, env->ninl[l], env->noutl[l], env->Kl[l], sx, sy, oy, ox, st));
     }
     ah.valid = false;
     env->gather_next[l] = false;
-    const int splits = gemm_splits(env->E, env->nout, env->K);
+    const int splits = gemm_splits(env->E, env->noutl[l], env->Kl[l]);
     MtAhead m{env->mt_cur[l], env->pos_cur[l], env->mt_alt[l], env->pos_alt[l], static_cast<float*>(env->zx_pipe_ptr(1 - cur, l)),
-              env->K, env->nin, env->nout, env->E};
+              env->Kl[l], env->ninl[l], env->noutl[l], env->E};
     {
         AO_PROF(env, GEMM_RING, st);
-        AO_TRY(launch_ring_gemm_draw_ahead(op, env->as<float>(env->ab), static_cast<float*>(env->xbuf_ptr(l)), env->E, env->nout, env->K,
+        AO_TRY(launch_ring_gemm_draw_ahead(op, env->as<float>(env->ab_l[l]), static_cast<float*>(env->xbuf_ptr(l)), env->E, env->noutl[l], env->Kl[l],
                                            splits, m, st));
     }
     env->last_zx = op;
+    env->last_zx_layer = l;
     env->org[l][0] = ((oy - sy) % S + S) % S;                      // the shift itself: move the origin of the torus
     env->org[l][1] = ((ox - sx) % S + S) % S;
     env->ring_pending[l] = splits;
@@ -414,16 +427,17 @@ int advance_atmosphere_env(AoEnv* env, bool lean, hipStream_t st) {
         const size_t row = (size_t)l * env->E;
         {
             AO_PROF(env, SHIFT_GATHER, st);
-            AO_TRY(launch_ring_prepare_env<T>(map, zx, env->inner_idx, env->mt_cur[l], env->pos_cur[l], env->env_clk[env->clk_cur] + row,
+            AO_TRY(launch_ring_prepare_env<T>(map, zx, env->inner_idx_l[l], env->mt_cur[l], env->pos_cur[l], env->env_clk[env->clk_cur] + row,
                                               env->env_clk[1 - env->clk_cur] + row, env->env_taps + row, env->layer_weight[l], env->E,
-                                              env->S, env->nin, env->nout, env->K, st));
+                                              env->Sl[l], env->ninl[l], env->noutl[l], env->Kl[l], st));
         }
         int splits = 1;
         {
             AO_PROF(env, GEMM_RING, st);
-            AO_TRY(gemm_dispatch<T>(env, zx, env->as<T>(env->ab), env->as<T>(env->xbuf_ptr(l)), env->E, env->nout, env->K, &splits, st));
+            AO_TRY(gemm_dispatch<T>(env, zx, env->as<T>(env->ab_l[l]), env->as<T>(env->xbuf_ptr(l)), env->E, env->noutl[l], env->Kl[l], &splits, st));
         }
         env->last_zx = zx;
+        env->last_zx_layer = l;
         env->ring_pending[l] = splits;
         env->ring_src[l] = env->xbuf_ptr(l);
         if (!(lean && env->defer_ring)) AO_TRY(flush_ring<T>(env, l, st));
@@ -634,7 +648,7 @@ bool fused_step_ok(const AoEnv*) { return false; }
 template <>
 bool fused_step_ok<float>(const AoEnv* env) {
     return env->use_fused_step && env->use_fast_wfs && env->use_mfma && env->use_fused_tail && env->c.wfs_type == AOENV_WFS_SH && env->c.dm_separable && env->n_modes > 0 &&
-           env->c.max_group == 1 && env->L > 0 && env->c.cam_res == env->R && env->debug_ablate == 0 &&
+           env->c.max_group == 1 && env->L > 0 && env->uniform && env->c.cam_res == env->R && env->debug_ablate == 0 &&
            step_fused_supported(env->R, env->nSub, env->nVal, env->nAct, env->n_modes) != 0;
 }
 
@@ -644,6 +658,10 @@ void fill_phase_args(AoEnv* env, PhaseArgs& pa, PhaseBuffers<T>& pb, int update_
     pa.n_layer = env->L;
     pa.S = env->S;
     pa.foot = (env->N / 2 - env->R / 2) + 1;
+    for (int l = 0; l < env->L; ++l) {                            // the R x R footprint of an on-axis source in layer l's grid
+        pa.S_l[l] = env->Sl[l];                                    // (OOPAO/Atmosphere.py:226-232: centre N_l // 2)
+        pa.foot_l[l] = (env->Nl[l] / 2 - env->R / 2) + 1;
+    }
     pa.update_atm = (update_atm && env->L > 0 && !env->atm_user_defined) ? 1 : 0;
     pa.store_atm = store_atm;
     pa.store_phase = store_phase;
@@ -808,7 +826,7 @@ struct BufInfo {
 int buf_info(AoEnv* env, int which, BufInfo* b) {
     const size_t z = env->esz, E = env->E, R2 = (size_t)env->R * env->R;
     switch (which) {
-        case AOENV_B_SCREEN: *b = {nullptr, (size_t)env->L * E * env->S * env->S * z}; return 0;   // gathered per layer
+        case AOENV_B_SCREEN: *b = {nullptr, env->scr_off[env->L] * z}; return 0;   // gathered per layer: [E][S_l^2] blocks, layer after layer
         case AOENV_B_OPD_ATM: *b = {env->opd_atm, E * R2 * z}; return 0;
         case AOENV_B_COEFS: *b = {env->coefs, E * env->A * z}; return 0;
         case AOENV_B_PHASE: *b = {env->phase, E * R2 * z}; return 0;
@@ -817,7 +835,7 @@ int buf_info(AoEnv* env, int which, BufInfo* b) {
         case AOENV_B_TOTAL: *b = {env->total, (size_t)env->c.n_loop * E * z}; return 0;
         case AOENV_B_RESIDUAL: *b = {env->residual, (size_t)env->c.n_loop * E * z}; return 0;
         case AOENV_B_WFS_MAX: *b = {env->wfs_max, E * z}; return 0;
-        case AOENV_B_XI: *b = {env->last_zx ? const_cast<void*>(env->last_zx) : env->zx, E * env->K * z}; return 0;
+        case AOENV_B_XI: *b = {env->last_zx ? const_cast<void*>(env->last_zx) : env->zx, E * env->Kl[env->last_zx_layer] * z}; return 0;
         case AOENV_B_MT_STATE: *b = {nullptr, (size_t)env->L * E * (kMtN + 1) * 4}; return 0;     // packed on the host
         case AOENV_B_COUNTERS: *b = {nullptr, 16}; return 0;
         case AOENV_B_DM_PREV: *b = {env->dm_prev, E * env->A * z}; return 0;
@@ -845,6 +863,34 @@ struct DeviceGuard {
     if (!(env)) return fail("null AoEnv");                                            \
     DeviceGuard ao_device_guard((env)->device);                                       \
     if (!ao_device_guard.ok) return fail("hipSetDevice(%d) failed", (env)->device)
+// the ring tables of ONE layer: [A | B] (float64 [n_outer_l][n_inner_l + n_outer_l]) or the flat indices of its Z / X pixels
+static int upload_layer_table(AoEnv* env, int kind, int l, const void* h, size_t bytes) {
+    if (l < 0 || l >= env->L) return fail("layer %d outside [0, %d)", l, env->L);
+    const int S = env->Sl[l], N = env->Nl[l];
+    auto need = [&](size_t n) { return bytes == n ? 0 : fail("ring table %d of layer %d: got %zu bytes, expected %zu", kind, l, bytes, n); };
+    if (kind == AOENV_C_AB) {
+        AO_TRY(need((size_t)env->noutl[l] * env->Kl[l] * 8));
+        AO_TRY(sync_lookaheads(env));                              // a ring computed ahead used the old operators
+        AO_TRY(upload_real(env, env->ab_l[l], static_cast<const double*>(h), (size_t)env->noutl[l] * env->Kl[l]));
+        env->have_ab[l] = true;
+        return 0;
+    }
+    if (kind != AOENV_C_INNER_IDX && kind != AOENV_C_OUTER_IDX) return fail("table %d is not a per-layer table", kind);
+    const int cnt = kind == AOENV_C_INNER_IDX ? env->ninl[l] : env->noutl[l];
+    AO_TRY(need((size_t)cnt * 4));
+    const int32_t* ix = static_cast<const int32_t*>(h);
+    for (int i = 0; i < cnt; ++i)
+        if (ix[i] < 0 || ix[i] >= S * S) return fail("ring index %d out of the %dx%d screen", ix[i], S, S);
+    if (kind == AOENV_C_INNER_IDX)          // the gather reads idx - sy*S - sx with |s| <= 1
+        for (int i = 0; i < cnt; ++i) {
+            const int r = ix[i] / S, c = ix[i] % S;
+            if (r < 1 || r > N || c < 1 || c > N) return fail("inner ring index %d is not interior", ix[i]);
+        }
+    AO_HIP(hipMemcpy(kind == AOENV_C_INNER_IDX ? env->inner_idx_l[l] : env->outer_idx_l[l], h, (size_t)cnt * 4, hipMemcpyHostToDevice));
+    (kind == AOENV_C_INNER_IDX ? env->have_in[l] : env->have_out[l]) = true;
+    return 0;
+}
+
 template <typename T>
 int atm_update_t(AoEnv* env, hipStream_t st) {
     AO_TRY(advance_atmosphere<T>(env, false, st));
@@ -870,6 +916,9 @@ int aoenv_create(const AoCfg* cfg, int device, AoEnv** out) {
         if (cfg->layer_res < cfg->resolution + 4) return fail("layer_res %d < R + 4", cfg->layer_res);
         if (cfg->n_inner != 8 * cfg->layer_res - 16 || cfg->n_outer != 4 * cfg->layer_res + 4)
             return fail("n_inner / n_outer do not match layer_res");
+        for (int l = 0; l < cfg->n_layer; ++l)
+            if (cfg->layer_res_l[l] != 0 && cfg->layer_res_l[l] < cfg->resolution + 4)
+                return fail("layer_res_l[%d] = %d < R + 4", l, cfg->layer_res_l[l]);
     }
     if (cfg->n_signal != 2 * cfg->n_valid_subap) return fail("n_signal != 2 n_valid_subap");
     if (cfg->wfs_type != AOENV_WFS_SH && cfg->wfs_type != AOENV_WFS_PYRAMID) return fail("unknown wfs_type %d", cfg->wfs_type);
@@ -895,22 +944,51 @@ int aoenv_create(const AoCfg* cfg, int device, AoEnv** out) {
     e->nAct = cfg->n_act; e->E = cfg->n_env; e->L = cfg->n_layer; e->nin = cfg->n_inner; e->nout = cfg->n_outer;
     e->K = cfg->n_inner + cfg->n_outer; e->nSig = cfg->n_signal; e->nSub = cfg->n_subap; e->nVal = cfg->n_valid_subap;
     e->p = e->R / e->nSub; e->n = 2 * e->p;
+    for (int l = 0; l < e->L; ++l) {
+        e->Nl[l] = cfg->layer_res_l[l] ? cfg->layer_res_l[l] : cfg->layer_res;
+        e->Sl[l] = e->Nl[l] + 2;
+        e->ninl[l] = 8 * e->Nl[l] - 16;
+        e->noutl[l] = 4 * e->Nl[l] + 4;
+        e->Kl[l] = e->ninl[l] + e->noutl[l];
+        e->scr_off[l + 1] = e->scr_off[l] + (size_t)e->E * e->Sl[l] * e->Sl[l];
+        e->Kmax = std::max(e->Kmax, e->Kl[l]);
+        e->noutmax = std::max(e->noutmax, e->noutl[l]);
+        e->Smax = std::max(e->Smax, e->Sl[l]);
+        if (e->Nl[l] != e->Nl[0]) e->uniform = false;
+    }
+    if (e->L > 0) {                                                // "layer 0" scalars: the grid of every layer when uniform
+        e->N = e->Nl[0]; e->S = e->Sl[0]; e->nin = e->ninl[0]; e->nout = e->noutl[0]; e->K = e->Kl[0];
+    }
     const size_t z = e->esz, E = e->E, R2 = (size_t)e->R * e->R;
     int rc = 0;
     auto A_ = [&](void** p, size_t bytes) { if (!rc) rc = dmalloc(e, p, bytes); };
     if (e->L > 0) {
-        A_(&e->screen[0], (size_t)e->L * E * e->S * e->S * z);
+        A_(&e->screen[0], e->scr_off[e->L] * z);
         A_(&e->minmax, (size_t)e->L * E * 2 * z);
         A_((void**)&e->mt_state, (size_t)2 * e->L * E * kMtN * 4);
         A_((void**)&e->mt_pos, (size_t)2 * e->L * E * 4);
         if (cfg->dtype == AOENV_F32) {                              // ring pipeline (fused float32 path)
-            A_(&e->zx_pipe, (size_t)2 * e->L * E * e->K * z);
+            A_(&e->zx_pipe, (size_t)2 * e->L * E * e->Kmax * z);
         }
-        A_(&e->zx, E * e->K * z);
-        A_(&e->xbuf, (size_t)e->L * kMaxSplits * E * e->nout * z);
-        A_(&e->ab, (size_t)e->nout * e->K * z);
-        A_((void**)&e->inner_idx, (size_t)e->nin * 4);
-        A_((void**)&e->outer_idx, (size_t)e->nout * 4);
+        A_(&e->zx, E * e->Kmax * z);
+        A_(&e->xbuf, (size_t)e->L * kMaxSplits * E * e->noutmax * z);
+        for (int l = 0; l < e->L; ++l) {                           // layers on the same grid share one set of tables
+            int same = -1;
+            for (int j = 0; j < l; ++j)
+                if (e->Nl[j] == e->Nl[l]) { same = j; break; }
+            if (same >= 0 && e->uniform) {                         // (non-uniform shards: operators per layer -- r0 / L0 scale them alike, but
+                e->ab_l[l] = e->ab_l[same];                        //  the reference computes them per layer too when fov != 0)
+                e->inner_idx_l[l] = e->inner_idx_l[same];
+                e->outer_idx_l[l] = e->outer_idx_l[same];
+                continue;
+            }
+            A_(&e->ab_l[l], (size_t)e->noutl[l] * e->Kl[l] * z);
+            A_((void**)&e->inner_idx_l[l], (size_t)e->ninl[l] * 4);
+            A_((void**)&e->outer_idx_l[l], (size_t)e->noutl[l] * 4);
+        }
+        e->ab = e->ab_l[0];
+        e->inner_idx = e->inner_idx_l[0];
+        e->outer_idx = e->outer_idx_l[0];
     }
     A_(&e->gx, (size_t)e->R * e->nAct * z);
     A_(&e->gy, (size_t)e->R * e->nAct * z);
@@ -1003,6 +1081,13 @@ int aoenv_create(const AoCfg* cfg, int device, AoEnv** out) {
     return 0;
 }
 
+int aoenv_upload_layer(AoEnv* env, int kind, int layer, const void* h, size_t bytes) {
+    AO_CHECK_ENV(env);
+    if (!h) return fail("aoenv_upload_layer: null data");
+    if (env->L == 0) return fail("no atmosphere in this shard");
+    return upload_layer_table(env, kind, layer, h, bytes);
+}
+
 int aoenv_destroy(AoEnv* env) {
     if (!env) return 0;
     DeviceGuard ao_device_guard(env->device);
@@ -1030,27 +1115,18 @@ int aoenv_upload(AoEnv* env, int kind, const void* h, size_t bytes) {
             break;
         }
         case AOENV_C_AB:
-            if (env->L == 0) return fail("no atmosphere in this shard");
-            AO_TRY(need((size_t)env->nout * env->K * 8));
-            AO_TRY(sync_lookaheads(env));                          // a ring computed ahead used the old operators
-            AO_TRY(upload_real(env, env->ab, d, (size_t)env->nout * env->K));
-            break;
         case AOENV_C_INNER_IDX:
-        case AOENV_C_OUTER_IDX: {
+        case AOENV_C_OUTER_IDX:
+            // one set of ring tables for every layer: shards whose layers share one grid (fov = 0, or no layer above the ground)
             if (env->L == 0) return fail("no atmosphere in this shard");
-            const int cnt = kind == AOENV_C_INNER_IDX ? env->nin : env->nout;
-            AO_TRY(need((size_t)cnt * 4));
-            const int32_t* ix = static_cast<const int32_t*>(h);
-            for (int i = 0; i < cnt; ++i)
-                if (ix[i] < 0 || ix[i] >= env->S * env->S) return fail("ring index %d out of the %dx%d screen", ix[i], env->S, env->S);
-            if (kind == AOENV_C_INNER_IDX)          // the gather reads idx - sy*S - sx with |s| <= 1
-                for (int i = 0; i < cnt; ++i) {
-                    const int r = ix[i] / env->S, c = ix[i] % env->S;
-                    if (r < 1 || r > env->N || c < 1 || c > env->N) return fail("inner ring index %d is not interior", ix[i]);
-                }
-            AO_HIP(hipMemcpy(kind == AOENV_C_INNER_IDX ? env->inner_idx : env->outer_idx, h, (size_t)cnt * 4, hipMemcpyHostToDevice));
+            if (!env->uniform) return fail("the layers of this shard have grids of their own: upload the ring tables per layer (aoenv_upload_layer)");
+            AO_TRY(upload_layer_table(env, kind, 0, h, bytes));
+            for (int l = 1; l < env->L; ++l) {
+                if (kind == AOENV_C_AB) env->have_ab[l] = true;
+                else if (kind == AOENV_C_INNER_IDX) env->have_in[l] = true;
+                else env->have_out[l] = true;
+            }
             break;
-        }
         case AOENV_C_LAYER_WEIGHT:
             AO_TRY(need((size_t)env->L * 8));
             for (int l = 0; l < env->L; ++l) env->layer_weight[l] = d[l];
@@ -1319,9 +1395,11 @@ static int require_step_constants(AoEnv* env, bool atmosphere) {
         if (!env->have[k]) return fail("constant table %d has not been uploaded", k);
     if (env->c.dm_separable ? !(env->have[AOENV_C_DM_GX] && env->have[AOENV_C_DM_GY]) : !env->have[AOENV_C_DM_MODES])
         return fail("DM influence functions have not been uploaded");
-    if (atmosphere && env->L > 0)
-        for (int k : {AOENV_C_AB, AOENV_C_INNER_IDX, AOENV_C_OUTER_IDX, AOENV_C_LAYER_WEIGHT})
-            if (!env->have[k]) return fail("atmosphere table %d has not been uploaded", k);
+    if (atmosphere && env->L > 0) {
+        if (!env->have[AOENV_C_LAYER_WEIGHT]) return fail("atmosphere table %d has not been uploaded", (int)AOENV_C_LAYER_WEIGHT);
+        for (int l = 0; l < env->L; ++l)
+            if (!env->have_ab[l] || !env->have_in[l] || !env->have_out[l]) return fail("the ring tables of layer %d have not been uploaded", l);
+    }
     return 0;
 }
 
@@ -1360,18 +1438,22 @@ int aoenv_new_screens(AoEnv* env, const double* h_screens, const uint32_t* h_rin
     if (!h_ring_seeds) return fail("null ring seeds");
     hipStream_t st = static_cast<hipStream_t>(stream);
     AO_HIP(hipStreamSynchronize(st));
-    const int E = env->E, L = env->L, N = env->N, S = env->S;
-    if (!h_screens)
+    const int E = env->E, L = env->L;
+    if (!h_screens) {
+        if (env->per_env_wind) return fail("per-env clocks: the interior cannot be kept (every env has moved its own origin): hand the screens over");
         for (int l = 0; l < L; ++l)
             if (env->org[l][0] || env->org[l][1]) return fail("keeping the interior is only possible before the first shift");
+    }
     for (int l = 0; l < L; ++l) env->org[l][0] = env->org[l][1] = 0;
     if (h_screens) {
         // mapShift[~outerMask] = phase  (OOPAO/Atmosphere.py:585); the ring is drawn below
-        std::vector<char> host((size_t)E * S * S * env->esz);
+        std::vector<char> host;
+        size_t layer_base = 0;                                     // (layers with grids of their own: layer-major blocks)
         for (int l = 0; l < L; ++l) {
-            std::memset(host.data(), 0, host.size());
+            const int N = env->Nl[l], S = env->Sl[l];
+            host.assign((size_t)E * S * S * env->esz, 0);
             for (int e = 0; e < E; ++e) {
-                const double* src = h_screens + ((size_t)e * L + l) * N * N;
+                const double* src = env->uniform ? h_screens + ((size_t)e * L + l) * N * N : h_screens + layer_base + (size_t)e * N * N;
                 for (int r = 0; r < N; ++r)
                     for (int c = 0; c < N; ++c) {
                         const size_t o = (size_t)e * S * S + (size_t)(r + 1) * S + (c + 1);
@@ -1380,6 +1462,7 @@ int aoenv_new_screens(AoEnv* env, const double* h_screens, const uint32_t* h_rin
                     }
             }
             AO_HIP(hipMemcpy(env->screen_ptr(0, l), host.data(), host.size(), hipMemcpyHostToDevice));
+            layer_base += (size_t)E * N * N;
         }
     }
     return finish_new_screens(env, h_ring_seeds, st);
@@ -1412,62 +1495,67 @@ int aoenv_new_screens_device(AoEnv* env, const uint32_t* h_screen_seeds, const u
     if (!(r0 > 0) || !(L0 > 0) || !(pixel_size > 0)) return fail("r0, L0 and the pixel size must be positive");
     hipStream_t st = static_cast<hipStream_t>(stream);
     AO_HIP(hipStreamSynchronize(st));
-    const int E = env->E, L = env->L, N = env->N, S = env->S;
-    if (N % 2) return fail("the screen generator needs an even layer size, got %d", N);
+    const int E = env->E, L = env->L;
     for (int l = 0; l < L; ++l) env->org[l][0] = env->org[l][1] = 0;
-    const size_t N2 = (size_t)N * N;
-
-    // frequency-grid amplitude sqrt(PSD) del_f (phaseStats.py:209-222) and the 3 x 4 sub-harmonic terms (:277-309)
-    std::vector<double> amp(N2), sub(36), tw(2 * (size_t)N);
-    const double del_f = 1.0 / (N * pixel_size);
-    for (int y = 0; y < N; ++y)
-        for (int x = 0; x < N; ++x) {
-            const double fx = (x - N / 2.0) * del_f, fy = (y - N / 2.0) * del_f;
-            amp[(size_t)y * N + x] = std::sqrt(vk_psd(std::sqrt(fx * fx + fy * fy), r0, L0)) * del_f;
-        }
-    amp[(size_t)(N / 2) * N + N / 2] = 0;
-    const double D = N * pixel_size;
-    for (int p = 1; p <= 3; ++p) {
-        const double df = 1.0 / (std::pow(3.0, p) * D);
-        for (int i = 0; i < 2; ++i)
-            for (int j = 0; j < 2; ++j) {
-                const double fx = (j - 1) * df, fy = (i - 1) * df;
-                double* t = &sub[3 * (4 * (p - 1) + 2 * i + j)];
-                t[0] = (i == 1 && j == 1) ? 0.0 : std::sqrt(vk_psd(std::sqrt(fx * fx + fy * fy), r0, L0)) * df;
-                t[1] = fx;
-                t[2] = fy;
-            }
-    }
     const double pi = 3.14159265358979323846;
-    for (int k = 0; k < N; ++k) { tw[2 * k] = std::cos(2 * pi * k / N); tw[2 * k + 1] = -std::sin(2 * pi * k / N); }
-
-    ScreenArgs sa{};
-    AO_TRY(make_fft_plan(N, &sa.plan));
-    sa.N = N;
-    sa.delta = pixel_size;
-    const size_t per_env = 40 * N2;                                // normals + complex scratch + real screen, float64
-    int EC = (int)std::min<size_t>((size_t)E, std::max<size_t>(1, ((size_t)1 << 30) / per_env));
     TmpFree tmp;
-    double *d_amp, *d_sub, *d_tw, *d_nrm, *d_hi;
-    void* d_scr;
-    uint32_t* d_mt;
-    int* d_pos;
-    AO_TRY(tmp.get((void**)&d_amp, N2 * 8));
-    AO_TRY(tmp.get((void**)&d_sub, 36 * 8));
-    AO_TRY(tmp.get((void**)&d_tw, 2 * (size_t)N * 8));
-    AO_TRY(tmp.get((void**)&d_nrm, (size_t)EC * 2 * N2 * 8));
-    AO_TRY(tmp.get(&d_scr, (size_t)EC * N2 * 16));
-    AO_TRY(tmp.get((void**)&d_hi, (size_t)EC * N2 * 8));
-    AO_TRY(tmp.get((void**)&d_mt, (size_t)EC * kMtN * 4));
-    AO_TRY(tmp.get((void**)&d_pos, (size_t)EC * 4));
-    AO_HIP(hipMemcpy(d_amp, amp.data(), N2 * 8, hipMemcpyHostToDevice));
-    AO_HIP(hipMemcpy(d_sub, sub.data(), 36 * 8, hipMemcpyHostToDevice));
-    AO_HIP(hipMemcpy(d_tw, tw.data(), tw.size() * 8, hipMemcpyHostToDevice));
-    sa.amp = d_amp; sa.sub = d_sub; sa.tw = d_tw; sa.nrm = d_nrm; sa.hi = d_hi;
-    sa.scratch = reinterpret_cast<cx<double>*>(d_scr);
-    std::vector<uint32_t> keys((size_t)EC * kMtN);
-    std::vector<int> pos((size_t)EC, kMtN);
-    for (int l = 0; l < L; ++l)
+    int N_built = -1, EC = 1;
+    ScreenArgs sa{};
+    double *d_amp = nullptr, *d_sub = nullptr, *d_tw = nullptr, *d_nrm = nullptr, *d_hi = nullptr;
+    void* d_scr = nullptr;
+    uint32_t* d_mt = nullptr;
+    int* d_pos = nullptr;
+    std::vector<uint32_t> keys;
+    std::vector<int> pos;
+    for (int l = 0; l < L; ++l) {
+        const int N = env->Nl[l], S = env->Sl[l];
+        const size_t N2 = (size_t)N * N;
+        if (N != N_built) {                                        // tables of this grid size (every layer's when fov = 0)
+            // frequency-grid amplitude sqrt(PSD) del_f (phaseStats.py:209-222) and the 3 x 4 sub-harmonic terms (:277-309)
+            std::vector<double> amp(N2), sub(36), tw(2 * (size_t)N);
+            const double del_f = 1.0 / (N * pixel_size);
+            for (int y = 0; y < N; ++y)
+                for (int x = 0; x < N; ++x) {
+                    const double fx = (x - N / 2.0) * del_f, fy = (y - N / 2.0) * del_f;
+                    amp[(size_t)y * N + x] = std::sqrt(vk_psd(std::sqrt(fx * fx + fy * fy), r0, L0)) * del_f;
+                }
+            amp[(size_t)(N / 2) * N + N / 2] = 0;
+            const double D = N * pixel_size;
+            for (int p = 1; p <= 3; ++p) {
+                const double df = 1.0 / (std::pow(3.0, p) * D);
+                for (int i = 0; i < 2; ++i)
+                    for (int j = 0; j < 2; ++j) {
+                        const double fx = (j - 1) * df, fy = (i - 1) * df;
+                        double* t = &sub[3 * (4 * (p - 1) + 2 * i + j)];
+                        t[0] = (i == 1 && j == 1) ? 0.0 : std::sqrt(vk_psd(std::sqrt(fx * fx + fy * fy), r0, L0)) * df;
+                        t[1] = fx;
+                        t[2] = fy;
+                    }
+            }
+            for (int k = 0; k < N; ++k) { tw[2 * k] = std::cos(2 * pi * k / N); tw[2 * k + 1] = -std::sin(2 * pi * k / N); }
+            sa = ScreenArgs{};
+            AO_TRY(make_fft_plan(N, &sa.plan));
+            sa.N = N;
+            sa.delta = pixel_size;
+            const size_t per_env = 40 * N2;                        // normals + complex scratch + real screen, float64
+            EC = (int)std::min<size_t>((size_t)E, std::max<size_t>(1, ((size_t)1 << 30) / per_env));
+            AO_TRY(tmp.get((void**)&d_amp, N2 * 8));
+            AO_TRY(tmp.get((void**)&d_sub, 36 * 8));
+            AO_TRY(tmp.get((void**)&d_tw, 2 * (size_t)N * 8));
+            AO_TRY(tmp.get((void**)&d_nrm, (size_t)EC * 2 * N2 * 8));
+            AO_TRY(tmp.get(&d_scr, (size_t)EC * N2 * 16));
+            AO_TRY(tmp.get((void**)&d_hi, (size_t)EC * N2 * 8));
+            AO_TRY(tmp.get((void**)&d_mt, (size_t)EC * kMtN * 4));
+            AO_TRY(tmp.get((void**)&d_pos, (size_t)EC * 4));
+            AO_HIP(hipMemcpy(d_amp, amp.data(), N2 * 8, hipMemcpyHostToDevice));
+            AO_HIP(hipMemcpy(d_sub, sub.data(), 36 * 8, hipMemcpyHostToDevice));
+            AO_HIP(hipMemcpy(d_tw, tw.data(), tw.size() * 8, hipMemcpyHostToDevice));
+            sa.amp = d_amp; sa.sub = d_sub; sa.tw = d_tw; sa.nrm = d_nrm; sa.hi = d_hi;
+            sa.scratch = reinterpret_cast<cx<double>*>(d_scr);
+            keys.assign((size_t)EC * kMtN, 0u);
+            pos.assign((size_t)EC, kMtN);
+            N_built = N;
+        }
         for (int e0 = 0; e0 < E; e0 += EC) {
             const int ne = std::min(EC, E - e0);
             // the layer's own RandomState(seed + layer) draws normal(size=(N, N)) twice (real, imaginary parts)
@@ -1481,6 +1569,7 @@ int aoenv_new_screens_device(AoEnv* env, const uint32_t* h_screen_seeds, const u
             else AO_TRY(launch_screen<double>(sa, reinterpret_cast<double*>(map), S, st));
             AO_HIP(hipStreamSynchronize(st));                      // keys / pos are reused by the next chunk
         }
+    }
     return finish_new_screens(env, h_ring_seeds, st);
 }
 
@@ -1673,14 +1762,16 @@ int aoenv_download(AoEnv* env, int which, void* h_dst, size_t bytes, void* strea
         AO_TRY(AO_DISPATCH(env, flush_rings, env, st));
         AO_HIP(hipStreamSynchronize(st));
         // the device keeps every screen as a torus: hand back the logical layer.mapShift
-        const int S = env->S;
-        const size_t per = (size_t)env->E * S * S * env->esz, z = env->esz;
-        std::vector<char> tmp(per);
+        const size_t z = env->esz;
+        std::vector<char> tmp;
         std::vector<EnvClock> clk_h;
         if (env->per_env_wind) AO_TRY(pull_env_clocks(env, clk_h));
         for (int l = 0; l < env->L; ++l) {
+            const int S = env->Sl[l];
+            const size_t per = (size_t)env->E * S * S * z;
+            tmp.resize(per);
             AO_HIP(hipMemcpy(tmp.data(), env->screen_ptr(0, l), per, hipMemcpyDeviceToHost));
-            char* dst = static_cast<char*>(h_dst) + l * per;
+            char* dst = static_cast<char*>(h_dst) + env->scr_off[l] * z;
             for (int e = 0; e < env->E; ++e) {
                 const int oy = env->per_env_wind ? clk_h[(size_t)l * env->E + e].org[0] : env->org[l][0];
                 const int ox = env->per_env_wind ? clk_h[(size_t)l * env->E + e].org[1] : env->org[l][1];
@@ -1735,8 +1826,8 @@ int aoenv_upload_state(AoEnv* env, int which, const void* h_src, size_t bytes, v
         // logical layer.mapShift of every env: the tori restart at origin 0; the clip range is re-derived by its next consumer
         AO_TRY(sync_lookaheads(env));
         for (int l = 0; l < env->L; ++l) {
-            const size_t per = (size_t)env->E * env->S * env->S * env->esz;
-            AO_HIP(hipMemcpy(env->screen_ptr(0, l), static_cast<const char*>(h_src) + l * per, per, hipMemcpyHostToDevice));
+            const size_t per = (size_t)env->E * env->Sl[l] * env->Sl[l] * env->esz;
+            AO_HIP(hipMemcpy(env->screen_ptr(0, l), static_cast<const char*>(h_src) + env->scr_off[l] * env->esz, per, hipMemcpyHostToDevice));
             env->org[l][0] = env->org[l][1] = 0;
             env->ring_pending[l] = 0;
             env->minmax_dirty[l] = true;

@@ -29,8 +29,10 @@ __device__ inline cx<T> tw_lds(const cx<T>* __restrict__ twl, int k, int inverse
 // outputs R apart (radix 16: 32 dwords = every lane in the same bank); with the padding lane j lands 17 slots after lane
 // j - 1.  Every buffer the transform touches -- the caller's input and the result included -- is indexed through fpad().
 __host__ __device__ inline int fpad(int i) { return i + (i >> 4); }
-// x / d for x < 2^16 with magic = floor(2^32 / d) + 1 (make_fft_plan)
-__device__ inline int fastdiv(int x, unsigned magic) { return (int)__umulhi((unsigned)x, magic); }
+// x / d for x < 2^16 with magic = floor(2^32 / d) + 1 (make_fft_plan, fft_magic); d = 1 has no such magic in 32 bits: magic 0 = "x itself"
+// (a one-stage plan of a prime length -- the 29-pixel screens of a small telescope with a field of view -- divides by m = 1)
+__device__ inline int fastdiv(int x, unsigned magic) { return magic ? (int)__umulhi((unsigned)x, magic) : x; }
+__host__ __device__ inline unsigned fft_magic(unsigned d) { return d <= 1u ? 0u : (unsigned)((1ull << 32) / d) + 1u; }
 
 // Length-4 DFT in place (forward: W_4 = -i; inverse: +i).
 template <typename T>

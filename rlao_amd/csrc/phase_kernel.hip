@@ -33,7 +33,7 @@ __device__ inline double wave_sum(double v) {
 template <typename T>
 __global__ void __launch_bounds__(256) k_phase(const KArgs<T> a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    const int R = a.R, nA = a.n_act, S = a.pa.S, TX = a.tx;
+    const int R = a.R, nA = a.n_act, TX = a.tx;
     const int MW = TX + 4;                                   // row stride of the staged layer tile (TX + 3 used)
     T* cimg = reinterpret_cast<T*>(lds_raw);                 // [nA][nA]
     T* s1 = cimg + nA * nA;                                  // [kTY][nA]
@@ -87,8 +87,9 @@ __global__ void __launch_bounds__(256) k_phase(const KArgs<T> a) {
     if (a.pa.update_atm) {
         for (int l = 0; l < a.pa.n_layer; ++l) {
             const LayerTaps& tp = layer_taps(a.pa, l, e);
+            const int S = a.pa.S_l[l], foot = a.pa.foot_l[l];       // the layer's own grid (fov != 0: it grows with the altitude)
             const T* map = static_cast<const T*>(a.pa.screen[l]) + (size_t)e * S * S;
-            const int r0 = y0 + a.pa.foot + tp.dy - 1, c0 = x0 + a.pa.foot + tp.dx - 1;
+            const int r0 = y0 + foot + tp.dy - 1, c0 = x0 + foot + tp.dx - 1;
             __syncthreads();                                  // previous layer's tiles are no longer read
             for (int r = ly; r < tye + 3; r += 4) {
                 const int rr = r0 + r;
@@ -235,7 +236,7 @@ __device__ inline void s1_tiles_mfma(const float* __restrict__ gya, int ga_strid
 
 __global__ void __launch_bounds__(256) k_phase_mfma(const KArgs<float> a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    const int R = a.R, nA = a.n_act, S = a.pa.S;
+    const int R = a.R, nA = a.n_act;
     constexpr int TX = kTXmax, MW = TX + 4;
     const int nAp = (nA + 3) & ~3, SS = nAp + 1;             // K padded to 4, s1 row stride odd (bank spread)
     const bool rows_given = a.pb.s1a != nullptr;             // Gy C already in HBM (k_dm_rows): no command image, no s1 here
@@ -292,8 +293,9 @@ __global__ void __launch_bounds__(256) k_phase_mfma(const KArgs<float> a) {
     if (a.pa.update_atm && !(a.ablate & 2)) {
         for (int l = 0; l < a.pa.n_layer; ++l) {
             const LayerTaps& tp = layer_taps(a.pa, l, e);
+            const int S = a.pa.S_l[l], foot = a.pa.foot_l[l];       // the layer's own grid (fov != 0: it grows with the altitude)
             const float* map = static_cast<const float*>(a.pa.screen[l]) + (size_t)e * S * S;
-            const int r0 = y0 + a.pa.foot + tp.dy - 1, c0 = x0 + a.pa.foot + tp.dx - 1;
+            const int r0 = y0 + foot + tp.dy - 1, c0 = x0 + foot + tp.dx - 1;
             __syncthreads();                                  // the previous layer's tile is no longer read
             {
                 constexpr int NV = ((kTY + 3) * MW + 255) / 256;      // 10 independent loads in flight per lane

@@ -195,7 +195,7 @@ int launch_psf(const PyrArgs<T>& base, T* psf, hipStream_t st) {
     a.seq_per_block = rb;
     hipLaunchKernelGGL((k_pyr_rows<T, 0>), dim3(cdiv(R, rb), 1, a.n_env), dim3(256), lds1, st, a);
     a.seq_per_block = cb;
-    a.magic_seq = (unsigned)((1ull << 32) / (unsigned)cb) + 1u;
+    a.magic_seq = fft_magic((unsigned)cb);
     hipLaunchKernelGGL(k_psf_cols<T>, dim3(N / cb, 1, a.n_env), dim3(256), lds2, st, a, psf);
     AO_HIP(hipGetLastError());
     return 0;
@@ -315,7 +315,7 @@ int launch_pyramid_n(const PyrArgs<T>& base, int n_theta, int chunk, hipStream_t
         a.seq_per_block = rb;
         hipLaunchKernelGGL((k_pyr_rows<T, NFIX12>), dim3(cdiv(R, rb), a.n_theta_chunk, a.n_env), dim3(256), lds1, st, a);
         a.seq_per_block = cb;
-        a.magic_seq = (unsigned)((1ull << 32) / (unsigned)cb) + 1u;
+        a.magic_seq = fft_magic((unsigned)cb);
         hipLaunchKernelGGL((k_pyr_cols<T, NFIX12>), dim3(cdiv(N / cb, 8) * 8, a.n_theta_chunk, a.n_env), dim3(256), lds2, st, a);
         a.seq_per_block = sb;
         hipLaunchKernelGGL((k_pyr_rows_inv<T, NFIX>), dim3(a.cam, a.n_env), dim3(256), lds3, st, a, t0 > 0 ? 1 : 0);
@@ -362,8 +362,8 @@ int make_fft_plan(int n, FftPlan* pl) {
         while (m % p == 0) { push(p); m /= p; }
     int prod = 1;
     for (int i = 0; i < pl->n_fac; ++i) {
-        pl->magic_ns[i] = (unsigned)((1ull << 32) / (unsigned)prod) + 1u;
-        pl->magic_m[i] = (unsigned)((1ull << 32) / (unsigned)(n / pl->fac[i])) + 1u;
+        pl->magic_ns[i] = fft_magic((unsigned)prod);
+        pl->magic_m[i] = fft_magic((unsigned)(n / pl->fac[i]));
         prod *= pl->fac[i];
     }
     if (n > 8192) return fail("FFT length %d too long for the 16-bit index arithmetic", n);

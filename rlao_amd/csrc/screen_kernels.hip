@@ -30,7 +30,7 @@ __global__ void __launch_bounds__(256) k_screen_rows(const ScreenArgs a) {
         const int r = i / N, x = i - r * N;
         cx<double> v = {0, 0};
         if (r < nrow) {
-            const int ys = (y0 + r + h) % N, xs = (x + h) % N;    // fftshift(cn)[y][x] = cn[(y + N/2) % N][(x + N/2) % N]
+            const int ys = (y0 + r + N - h) % N, xs = (x + N - h) % N;   // fftshift(cn)[y][x] = cn[(y - N//2) % N][(x - N//2) % N] (odd N too)
             const size_t q = (size_t)ys * N + xs;
             const double w = a.amp[q];
             v = {re[q] * w, im[q] * w};

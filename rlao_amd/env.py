@@ -56,11 +56,29 @@ class Shard:
 
     __del__ = close
 
-    def upload(self, kind: int, arr: np.ndarray):
+    def upload(self, kind: int, arr: np.ndarray, layer=None):
+        """``layer``: the ring tables (C_AB, C_INNER_IDX, C_OUTER_IDX) of that layer alone (layers on grids of their own)."""
         want = {L.C_PUPIL: np.uint8, L.C_INNER_IDX: np.int32, L.C_OUTER_IDX: np.int32, L.C_ACT_IDX: np.int32,
                 L.C_SH_SUBAP_IDX: np.int32}.get(kind, np.float64)
         a = np.ascontiguousarray(arr, dtype=want)
-        L.check(self.lib.aoenv_upload(self.h, kind, a.ctypes.data_as(C.c_void_p), a.nbytes))
+        if layer is None:
+            L.check(self.lib.aoenv_upload(self.h, kind, a.ctypes.data_as(C.c_void_p), a.nbytes))
+        else:
+            L.check(self.lib.aoenv_upload_layer(self.h, kind, int(layer), a.ctypes.data_as(C.c_void_p), a.nbytes))
+
+    def upload_ring_tables(self, at, only_ab=False):
+        """[A | B] and the ring index tables of every layer (calib.AtmosphereTables): one set when all layers share a grid."""
+        if at.uniform:
+            self.upload(L.C_AB, at.AB)
+            if not only_ab:
+                self.upload(L.C_INNER_IDX, at.inner_idx)
+                self.upload(L.C_OUTER_IDX, at.outer_idx)
+            return
+        for l, t in enumerate(at.layers):
+            self.upload(L.C_AB, t.AB, layer=l)
+            if not only_ab:
+                self.upload(L.C_INNER_IDX, t.inner_idx, layer=l)
+                self.upload(L.C_OUTER_IDX, t.outer_idx, layer=l)
 
     def set_wind(self, ratio: np.ndarray, reset_buff: bool):
         r = np.ascontiguousarray(ratio, dtype=np.float64)
@@ -190,7 +208,7 @@ class _AtmProxy:
         e = self._e
         e.param.r0 = float(val)
         e._atm_tables.set_r0(e.param.r0)
-        e._shard.upload(L.C_AB, e._atm_tables.AB)
+        e._shard.upload_ring_tables(e._atm_tables, only_ab=True)
 
     @property
     def nLayer(self):
@@ -464,10 +482,13 @@ class BatchedAOEnv:
             # (the parity tests inject the recorded operators to separate that from the device arithmetic)
             A_, B_ = (np.asarray(x, dtype=np.float64) for x in atm_AB)
             at = self._atm_tables
+            if not at.uniform:
+                raise ValueError("atm_AB: the layers of this atmosphere have grids (and operators) of their own")
             if A_.shape != at.A.shape or B_.shape != at.B.shape:
                 raise ValueError(f"atm_AB must have shapes {at.A.shape} and {at.B.shape}")
             at.A, at.B = A_, B_
             at.AB = np.ascontiguousarray(np.concatenate([A_, B_], axis=1))
+            at.layers[0].A, at.layers[0].B, at.layers[0].AB = at.A, at.B, at.AB
         self._dm_tables = dmt = (calib.DMTables(p) if not second_dm else
                                  calib.CompositeDM(p, int(second_dm["nSubaperture"])))
         self._dm_separable = 1 if dmt.gx is not None else 0
@@ -503,9 +524,7 @@ class BatchedAOEnv:
         self._shard = self._make_shard(self.n_envs, self.dtype, n_layer=p.nLayer, max_group=1)
         sh = self._shard
         at = self._atm_tables
-        sh.upload(L.C_AB, at.AB)
-        sh.upload(L.C_INNER_IDX, at.inner_idx)
-        sh.upload(L.C_OUTER_IDX, at.outer_idx)
+        sh.upload_ring_tables(at)
         sh.upload(L.C_LAYER_WEIGHT, at.weights)
         sh.upload(L.C_SH_REF, ref)
         sh.upload(L.C_WFS_UNITS, np.array([units]))
@@ -544,6 +563,8 @@ class BatchedAOEnv:
             pt = self._pyr_tables
             cfg.update(wfs_type=L.WFS_PYRAMID, pyr_n_res=pt.nRes, pyr_n_theta=self._wfs_n_theta,
                        pyr_centering=int(pt.psf_centering), pyr_norm_valid=pt.norm_valid, pyr_q_lo=pt.q_lo, pyr_q_hi=pt.q_hi)
+        if n_layer > 0 and not at.uniform:                          # fov != 0: a layer above the ground has a grid of its own
+            cfg["layer_res_l"] = (C.c_int32 * 8)(*(at.layer_res + [0] * (8 - len(at.layer_res))))
         sh = Shard(cfg, self.device_index)
         sh.upload(L.C_PUPIL, self.pupil.astype(np.uint8))
         if self._dm_separable:
@@ -718,11 +739,16 @@ class BatchedAOEnv:
         if screens is None:
             scr = np.array([[(int(s) + l) & 0xFFFFFFFF for l in range(p.nLayer)] for s in seeds], dtype=np.uint32)
             self._shard.new_screens_device(scr, ring, p.r0, p.L0, delta, self._stream())
-        else:
+        elif at.uniform:
             screens = np.asarray(screens, dtype=np.float64)
             if screens.shape != (self.n_envs, p.nLayer, at.N, at.N):
                 raise ValueError(f"screens must have shape ({self.n_envs}, {p.nLayer}, {at.N}, {at.N})")
             self._shard.new_screens(screens.reshape(self.n_envs, p.nLayer, at.N * at.N), ring, self._stream())
+        else:                                                       # one array [n_envs, N_l, N_l] per layer
+            if len(screens) != p.nLayer or any(np.shape(x) != (self.n_envs, n, n) for x, n in zip(screens, at.layer_res)):
+                raise ValueError(f"screens must be a list of per-layer arrays [{self.n_envs}, N_l, N_l] with N_l = {at.layer_res}")
+            flat = np.concatenate([np.asarray(x, dtype=np.float64).reshape(-1) for x in screens])
+            self._shard.new_screens(flat, ring, self._stream())
         if self._wind_env is not None:
             self.set_wind_per_env(reset=True)                       # every env keeps its own wind over the episodes
         else:
@@ -828,7 +854,7 @@ class BatchedAOEnv:
         sh, p, at = self._shard, self.param, self._atm_tables
         st = self._stream()
         return {
-            "screen": sh.download(L.B_SCREEN, (p.nLayer, self.n_envs, at.S, at.S), st),
+            "screen": self._download_screens(),
             "buff": None if self._per_env_clock else sh.get_buff(p.nLayer).copy(),
             "clock_env": sh.get_clock_env(p.nLayer, self.n_envs) if self._per_env_clock else None,
             "wind_env": self._wind_env,
@@ -850,13 +876,13 @@ class BatchedAOEnv:
             self._shard.set_wind_env(clk[..., :2], False, st)
             self._per_env_clock = True
             self._wind_env = state.get("wind_env")
-            sh.upload_state(L.B_SCREEN, state["screen"], st)
+            sh.upload_state(L.B_SCREEN, self._flat_screens(state["screen"]), st)
             sh.set_clock_env(clk)
         else:
             if self._per_env_clock:
                 raise ValueError("this env runs per-env clocks; the state was saved from a shared-clock env")
             self._push_wind(reset=False)
-            sh.upload_state(L.B_SCREEN, state["screen"], st)
+            sh.upload_state(L.B_SCREEN, self._flat_screens(state["screen"]), st)
             sh.set_buff(state["buff"])
         sh.upload_state(L.B_MT_STATE, state["mt"], st, dtype=np.uint32)
         sh.upload_state(L.B_COEFS, state["coefs"], st)
@@ -864,6 +890,23 @@ class BatchedAOEnv:
         sh.upload_state(L.B_SIGNAL, state["signal"], st)
         sh.upload_state(L.B_COUNTERS, state["counters"], st, dtype=np.uint32)
         self._obs = _torch().as_tensor(state["obs"]).to(device=self.device, dtype=self.tdtype).clone()   # (never into a handed-out tensor)
+
+    def _download_screens(self):
+        """layer.mapShift of every env: [nLayer, n_envs, S, S], or -- layers on grids of their own -- a list of [n_envs, S_l, S_l]."""
+        sh, p, at = self._shard, self.param, self._atm_tables
+        if at.uniform:
+            return sh.download(L.B_SCREEN, (p.nLayer, self.n_envs, at.S, at.S), self._stream())
+        sizes = [self.n_envs * t.S * t.S for t in at.layers]
+        flat = sh.download(L.B_SCREEN, (sum(sizes),), self._stream())
+        out, o = [], 0
+        for t, n in zip(at.layers, sizes):
+            out.append(flat[o:o + n].reshape(self.n_envs, t.S, t.S))
+            o += n
+        return out
+
+    @staticmethod
+    def _flat_screens(scr):
+        return scr if isinstance(scr, np.ndarray) else np.concatenate([np.asarray(x).reshape(-1) for x in scr])
 
     def accumulate_returns(self, tensor):
         """Attach a device tensor [n_envs] (env dtype) to which every step adds its reward (None detaches): the

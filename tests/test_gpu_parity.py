@@ -12,8 +12,9 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 # c3_pyr / c5_mcao: BASELINE.json configs[2] / configs[4] at their real per-env size (8 m 40x40 Pyramid, nRes 528; 3 layers + 2 DMs)
+# tiny_3layer_fov1: layers at 0 / 1000 / 5000 m under a telescope with fov = 1 arcsec: screen grids of 28, 29, 29 pixels (batched kernels)
 # c3_pyr_mod3: the 40x40 Pyramid with modulation 3 lambda/D (nTheta = 20, five chunks of four modulation points per measurement)
-CASES = ["tiny_sh", "tiny_fastwind", "tiny_3layer", "small_sh", "c2_sh", "tiny_pyr", "tiny_pyr_mod", "papyrus_pyr", "c3_pyr", "c3_pyr_mod3",
+CASES = ["tiny_sh", "tiny_fastwind", "tiny_3layer", "tiny_3layer_fov1", "small_sh", "c2_sh", "tiny_pyr", "tiny_pyr_mod", "papyrus_pyr", "c3_pyr", "c3_pyr_mod3",
          "c5_mcao"]
 
 # Stated tolerances of the step outputs (north_star: "within a stated fp32 tolerance"), absolute unless *_rel.
@@ -36,10 +37,12 @@ F64_SAME_OPERATOR_TOL = dict(obs=1e-12, reward_rel=1e-11, strehl=1e-13, rms_nm=1
 F64_TOL_BY_CASE = {
     "c2_sh": dict(obs=1.1e-07, signal=1.6e-05, strehl=7.0e-10, rms_nm=1.1e-06, opd_m=3.7e-13, frame_rel=3.1e-07, screen=1.2e-06, host_A=4.0e-10),
     "c3_pyr": dict(obs=3.3e-09, signal=9.6e-07, strehl=1.0e-10, rms_nm=2.5e-08, opd_m=9.5e-14, frame_rel=5.2e-08, screen=1.9e-05, host_A=5.1e-09),
+    "c3_pyr_mod3": dict(obs=3.3e-08, signal=9.6e-06, strehl=1.0e-09, rms_nm=2.5e-07, opd_m=9.5e-13, frame_rel=5.2e-07, screen=1.9e-05, host_A=5.1e-09),
     "c5_mcao": dict(obs=5.0e-08, signal=1.2e-06, strehl=1.0e-10, rms_nm=5.6e-08, opd_m=4.0e-14, frame_rel=4.4e-08, screen=3.2e-06, host_A=4.0e-10),
     "papyrus_pyr": dict(obs=2.8e-06, signal=2.0e-04, strehl=1.5e-06, rms_nm=4.3e-04, opd_m=5.5e-12, frame_rel=1.6e-05, screen=3.9e-06, host_A=5.6e-09),
     "small_sh": dict(obs=3.4e-07, signal=6.6e-06, strehl=3.4e-08, rms_nm=6.3e-05, opd_m=6.2e-13, frame_rel=5.1e-07, screen=1.5e-06, host_A=1.0e-11),
     "tiny_3layer": dict(obs=4.9e-09, signal=7.7e-08, strehl=2.7e-09, rms_nm=1.4e-06, opd_m=1.5e-14, frame_rel=2.0e-08, screen=1.5e-07, host_A=1.7e-12),
+    "tiny_3layer_fov1": dict(obs=4.9e-08, signal=7.7e-07, strehl=2.7e-08, rms_nm=1.4e-05, opd_m=1.5e-13, frame_rel=2.0e-07, screen=1.5e-06, host_A=1.7e-12),
     "tiny_fastwind": dict(obs=4.8e-08, signal=7.4e-07, strehl=3.9e-09, rms_nm=1.1e-05, opd_m=9.8e-14, frame_rel=1.3e-07, screen=1.1e-07, host_A=1.7e-12),
     "tiny_pyr": dict(obs=6.1e-09, signal=8.8e-07, strehl=6.4e-09, rms_nm=1.1e-06, opd_m=3.3e-14, frame_rel=5.7e-08, screen=9.9e-08, host_A=1.7e-12),
     "tiny_pyr_mod": dict(obs=4.1e-09, signal=2.5e-07, strehl=1.2e-09, rms_nm=2.1e-07, opd_m=9.1e-15, frame_rel=9.8e-09, screen=8.0e-08, host_A=1.7e-12),
@@ -65,6 +68,8 @@ def _params(g, **kw):
              nPixelPerSubap=int(g["cfg_R"]) // int(g["cfg_nsub"]), r0=float(g["cfg_r0"]), L0=float(g["cfg_L0"]),
              windSpeed=list(g["cfg_ws"]), windDirection=list(g["cfg_wd"]), fractionnalR0=list(g["cfg_frac"]),
              altitude=list(g["cfg_alt"]), nModes=int(g["cfg_n_modes"]), nLoop=64)
+    if "cfg_fov" in g:
+        d["fov"] = float(g["cfg_fov"])
     d.update(kw)
     return d
 
@@ -118,9 +123,11 @@ def _replay(env, g, tol, n_envs_seeds, label="?"):
     T = len(g[f"s{seeds[0]}_actions"])
     for k, s in enumerate(seeds):
         _close(obs0[k], g[f"s{s}_obs0"], "obs", tol, label)
-    scr = env._shard.download(0, (env.param.nLayer, env.n_envs, env._atm_tables.S, env._atm_tables.S))
+    scr = env._download_screens()                                 # [nLayer, n_envs, S, S], or per layer [n_envs, S_l, S_l] (fov != 0)
     for k, s in enumerate(seeds):
-        _close(scr[:, k], g[f"s{s}_mapShift0"], "screen", tol, label)
+        for l in range(env.param.nLayer):
+            S = env._atm_tables.layers[l].S
+            _close(scr[l][k], g[f"s{s}_mapShift0"][l][:S, :S], "screen", tol, label)
     for i in range(T):
         act = torch.as_tensor(np.stack([g[f"s{s}_actions"][i] for s in seeds]))
         obs, frame, rew, sr, done, info = env.step(i, act)
@@ -159,6 +166,8 @@ def test_golden_replay(name, dtype, golden_dir):
     label = f"{name}-{dtype}"
     inject = dtype == "f64-refAB"
     AB = None
+    if inject and "cfg_fov" in g:
+        pytest.skip("layers with operators of their own: the injection takes one pair")
     if inject:
         side = os.path.join(golden_dir, name + "_AB.npz")          # (c2_sh: the operators of the headline geometry, in full)
         if "A" in g:

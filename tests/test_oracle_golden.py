@@ -11,7 +11,8 @@ import pytest
 
 from oracle import ao_oracle as O
 
-CASES = ["tiny_sh", "tiny_fastwind", "tiny_3layer", "small_sh", "c2_sh", "tiny_pyr", "tiny_pyr_mod", "papyrus_pyr", "c5_mcao"]
+# tiny_3layer_fov1: layers at 0 / 1000 / 5000 m under the reference env's own telescope (fov = 1 arcsec): grids of 28, 29, 29 pixels
+CASES = ["tiny_sh", "tiny_fastwind", "tiny_3layer", "tiny_3layer_fov1", "small_sh", "c2_sh", "tiny_pyr", "tiny_pyr_mod", "papyrus_pyr", "c5_mcao"]
 
 
 def _env_from_golden(g, **extra):
@@ -20,6 +21,8 @@ def _env_from_golden(g, **extra):
         kw.update(wfs_type="pyramid", modulation=float(g["cfg_modulation"]), psf_centering=bool(g["cfg_centering"]))
     if "cfg_second_nsub" in g:
         kw.update(second_dm_nsub=int(g["cfg_second_nsub"]))
+    if "cfg_fov" in g:
+        kw.update(fov_arcsec=float(g["cfg_fov"]))
     return O.OracleEnv(resolution=int(g["cfg_R"]), diameter=float(g["cfg_D"]), n_subap=int(g["cfg_nsub"]),
                        r0=float(g["cfg_r0"]), L0=float(g["cfg_L0"]), windSpeed=list(g["cfg_ws"]),
                        windDirection=list(g["cfg_wd"]), fractionalR0=list(g["cfg_frac"]),
@@ -48,6 +51,11 @@ def test_constants(case):
         np.testing.assert_allclose(env.wfs.reference_slopes_maps, g["reference_slopes_maps"], atol=1e-13)
         np.testing.assert_allclose(env.wfs.slopes_units, float(g["slopes_units"]), rtol=1e-11)
     lay = env.atm.layers[0]
+    if "cfg_layer_S" in g:                                      # fov != 0: every layer its own grid and ring operators
+        assert [l.mapShift.shape[0] for l in env.atm.layers] == list(g["cfg_layer_S"])
+        for i, l in enumerate(env.atm.layers[1:], start=1):
+            np.testing.assert_allclose(l.A, g[f"A_l{i}"], atol=1e-12)
+            np.testing.assert_allclose(l.B, g[f"B_l{i}"], atol=1e-12)
     if "A" in g:
         np.testing.assert_allclose(lay.A, g["A"], atol=1e-12)
         np.testing.assert_allclose(lay.B, g["B"], atol=1e-12)
@@ -82,7 +90,9 @@ def test_closed_loop_replay(case):
         p = f"s{int(seed)}_"
         env.dm_prev[:] = 0                                      # every recorded episode is the first one of a fresh env
         env.new_episode(int(seed))
-        np.testing.assert_allclose(env.atm.layers[0].mapShift, g[p + "mapShift0"][0], atol=1e-12)
+        for l, lay in enumerate(env.atm.layers):
+            S = lay.mapShift.shape[0]
+            np.testing.assert_allclose(lay.mapShift, g[p + "mapShift0"][l][:S, :S], atol=1e-12)
         np.testing.assert_allclose(env.reset_soft(), g[p + "obs0"], atol=1e-11)
         full = {int(s): k for k, s in enumerate(g[p + "full_steps"])}
         acts = g[p + "actions"]
