@@ -75,13 +75,21 @@ __device__ inline void camera_sh6_lane(f32x16s& pxv, bool ok, uint32_t px0, int 
                 quad_bits(qid, e, det, kDrawPhoton2, o2);
                 if (__any(fmaxf(fmaxf(v4[0], v4[1]), fmaxf(v4[2], v4[3])) >= palias::kCoarseStep)) quad_bits(qid, e, det, kDrawPhoton3, o3);
             }
+            float lam4[4], k4[4];
 #pragma unroll
             for (int sl = 0; sl < 4; ++sl) {
                 const bool ov = v4[sl] >= lmax;
                 over |= ov ? 1u << (4 * t + sl) : 0u;
-                const float k = AO_ABL(1) ? v4[sl] : poisson_alias<true>(ov ? 0.f : v4[sl], o[sl], o2[sl], o3[sl], tab);
-                pxv[sl] = ov ? v4[sl] : k;
+                lam4[sl] = ov ? 0.f : v4[sl];
             }
+            if (AO_ABL(1)) {
+#pragma unroll
+                for (int sl = 0; sl < 4; ++sl) k4[sl] = v4[sl];
+            } else {
+                poisson_alias4(lam4, o, o2, o3, tab, k4);
+            }
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) pxv[sl] = v4[sl] >= lmax ? v4[sl] : k4[sl];
             camera_rotate(pxv);
         }
         if (__any(over != 0u)) {                                      // (a very bright star: rare at the flux of the BASELINE configs)

@@ -206,11 +206,17 @@ __device__ inline void photon_quad(f32x4d& v, const uint32_t (&o)[4], const uint
                                    uint32_t env, const DetectorCfg& d, float lmax, const uint32_t* __restrict__ tab) {
     f32x4d k;
     bool over = false;
+    {
+        float lam[4], out[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const bool ov = v[s] >= lmax;
-        over = over || ov;
-        k[s] = poisson_alias<true>(ov ? 0.f : v[s], o[s], o2[s], o3[s], tab);
+        for (int s = 0; s < 4; ++s) {
+            const bool ov = v[s] >= lmax;
+            over = over || ov;
+            lam[s] = ov ? 0.f : v[s];
+        }
+        poisson_alias4(lam, o, o2, o3, tab, out);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) k[s] = out[s];
     }
     if (__any(over)) {
         const u32x4d ov = {o[0], o[1], o[2], o[3]}, o3v = {o3[0], o3[1], o3[2], o3[3]};

@@ -503,6 +503,19 @@ int apply_detector(AoEnv* env, bool sh, hipStream_t st) {
                               env->c.cam_res, env->nSub, env->det, env->alias(), st);
 }
 
+// Shack-Hartmann spots, then the camera on the frame (self*self.cam, OOPAO/ShackHartmann.py:539-576).  [Round 3 measured the camera
+// INSIDE the spots kernel once more (16-wave workgroups, alias tables in LDS, the noisy frame written once, bit-identical): 1140 us
+// against 611 + 463 us for the two kernels at the ELT size -- both are bound by vector instructions, not by the frame's round trip.]
+template <typename T>
+int run_spots_and_camera(AoEnv* env, const ShConst<T>& sc, hipStream_t st) {
+    {
+        AO_PROF(env, SH_SPOTS, st);
+        AO_TRY(launch_sh_spots<T>(env->as<T>(env->phase), sc, env->as<T>(env->frame), env->as<T>(env->wfs_max), env->E,
+                                  env->R, env->nSub, env->nVal, st));
+    }
+    return apply_detector<T>(env, true, st);
+}
+
 template <typename T>
 int run_wfs(AoEnv* env, hipStream_t st) {
     if (env->c.wfs_type == AOENV_WFS_PYRAMID) {
@@ -543,12 +556,7 @@ int run_wfs(AoEnv* env, hipStream_t st) {
         return launch_pyramid_slopes<T>(sl, env->E, st);
     }
     const ShConst<T> sc = sh_const<T>(env);
-    {
-        AO_PROF(env, SH_SPOTS, st);
-        AO_TRY(launch_sh_spots<T>(env->as<T>(env->phase), sc, env->as<T>(env->frame), env->as<T>(env->wfs_max), env->E,
-                                  env->R, env->nSub, env->nVal, st));
-    }
-    AO_TRY(apply_detector<T>(env, true, st));                      // self*self.cam (OOPAO/ShackHartmann.py:576)
+    AO_TRY(run_spots_and_camera<T>(env, sc, st));                  // spots, self*self.cam (OOPAO/ShackHartmann.py:539-576)
     {
         AO_PROF(env, SH_CENTROID, st);
         AO_TRY(launch_sh_centroid<T>(env->as<T>(env->frame), env->as<T>(env->wfs_max), sc, env->as<T>(env->signal),
@@ -780,12 +788,7 @@ int step_t(AoEnv* env, int i, const void* d_action, void* d_obs, void* d_frame, 
     const bool fused = env->c.wfs_type == AOENV_WFS_SH && env->use_fused_tail && env->n_modes > 0 && env->E <= 1024;
     if (fused) {
         const ShConst<T> sc = sh_const<T>(env);
-        {
-            AO_PROF(env, SH_SPOTS, st);
-            AO_TRY(launch_sh_spots<T>(env->as<T>(env->phase), sc, env->as<T>(env->frame), env->as<T>(env->wfs_max), env->E,
-                                      env->R, env->nSub, env->nVal, st));
-        }
-        AO_TRY(apply_detector<T>(env, true, st));
+        AO_TRY(run_spots_and_camera<T>(env, sc, st));
         FinishArgs<T> fa = finish_args<T>(env, static_cast<const T*>(d_action), static_cast<T*>(d_obs),
                                           static_cast<T*>(d_reward), static_cast<T*>(d_strehl), i, 1, gain, 1);
         int rc;
@@ -1379,6 +1382,9 @@ int aoenv_set_wind(AoEnv* env, const double* h_ratio, int reset_buff) {
                 r[2 * ((size_t)l * env->E + e)] = h_ratio[2 * l];
                 r[2 * ((size_t)l * env->E + e) + 1] = h_ratio[2 * l + 1];
             }
+        // (this entry point has no stream argument: the caller may be stepping on a non-blocking stream, whose pending ring /
+        //  clock work must be through before the clocks are pulled, changed and pushed back on the null stream)
+        AO_HIP(hipDeviceSynchronize());
         return aoenv_set_wind_env(env, r.data(), reset_buff, nullptr);
     }
     for (int l = 0; l < env->L; ++l) {

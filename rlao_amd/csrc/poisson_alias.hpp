@@ -15,10 +15,11 @@
 //           word w picks the cell floor(w n / 2^32) and compares the product's low bits with the cell's 23-bit threshold -- ONE
 //           table read per draw, no loop.  128 fine rows + 32 coarse rows = 14.9 k words (58 KB): resident in LDS where a
 //           workgroup draws thousands of pixels (fused step kernel, k_detector_sh6), read through the caches otherwise.
-//   Xd:     inversion with 7 unrolled steps (P(Poisson(1/4) > 7) = 1e-10, below the resolution of the uniform).
+//   Xd:     inversion, at most 7 steps (P(Poisson(1/4) > 7) = 1e-10, below the resolution of the uniform), the lanes of a wave in
+//           lock-step with a vote per step: P(Xd > 1) < 3 %, so a wave usually leaves after two or three.
 //
-// Three words per pixel (two below 32 photons), ~45 lane-instructions, no votes, no queues, no divergence: the lanes of a wave
-// finish together whatever their pixels hold.  Probabilities are exact to the quantisation of the thresholds, 2^-23 / n of a row's
+// Three words per pixel (two below 32 photons), ~50 lane-instructions, no queues, no divergence: the lanes of a wave finish
+// together whatever their pixels hold.  Probabilities are exact to the quantisation of the thresholds, 2^-23 / n of a row's
 // mass per outcome (n >= 1 cells) -- the level of the float32 inversion it replaces.  Pixels at or above the table's end (`lmax`,
 // 1024 photons at full size) go through PTRS (detector.hpp), whole waves at a time: rare at the flux of the BASELINE configs
 // (brightest pixel of the 8 m / 20x20 loop at magnitude 8: ~860 photons).
@@ -69,31 +70,65 @@ __device__ inline uint32_t alias_draw(const uint32_t* __restrict__ tab, int row,
     const uint64_t prod = (uint64_t)w * n;                         // v_mad_u64_u32: cell and the fraction inside it in one instruction
     const uint32_t cell = (uint32_t)(prod >> 32), frac = (uint32_t)prod;
     const uint32_t en = tab[d.x + cell];
-    return kmin + ((frac >> 9) < (en >> 9) ? cell : (en & 511u));
+    return kmin + (frac < (en & ~511u) ? cell : (en & 511u));       // (frac >> 9) < threshold
 }
 
 __device__ inline float u01_23(uint32_t x) { return ((float)(x >> 9) + 0.5f) * (1.0f / 8388608.0f); }   // strictly inside (0, 1)
 
-// Poisson(lam), 0 <= lam < lmax of the table `tab` points to (LDS or global).  wf, wr, wc: independent 32-bit words (wc is only
-// looked at where lam >= 32).  COARSE = false: the caller knows lam < 32 for every lane.
-template <bool COARSE = true>
-__device__ inline float poisson_alias(float lam, uint32_t wf, uint32_t wr, uint32_t wc, const uint32_t* __restrict__ tab) {
+// The three parts of one draw, split so that a caller with several pixels per lane can run the remainders of all of them in ONE
+// loop with a wave vote per step (below): lam = 32 c + j / 4 + d.
+struct AliasParts { int fine_row, coarse_row; float d; };
+__device__ inline AliasParts alias_parts(float lam) {
     const float c = floorf(lam * (1.0f / palias::kCoarseStep));
     const float r = fmaf(-palias::kCoarseStep, c, lam);                               // exact: [0, 32)
     const float jf = fminf(floorf(r * (1.0f / palias::kFineStep)), (float)(palias::kFineRows - 1));
-    const float dl = fmaxf(fmaf(-palias::kFineStep, jf, r), 0.f);                      // exact: [0, 1/4)
-    uint32_t k = alias_draw(tab, (int)jf, wf);
-    if (COARSE) k += alias_draw(tab, palias::kFineRows + (int)c, wc);
-    // the remainder: inversion, P(t + 1) = P(t) d / (t + 1)
-    float p = __expf(-dl), cdf = p;
-    const float u = u01_23(wr);
+    return {(int)jf, palias::kFineRows + (int)c, fmaxf(fmaf(-palias::kFineStep, jf, r), 0.f)};   // d exact: [0, 1/4)
+}
+
+// Poisson(d[s]), d < 1/4, for the NP pixels of a lane by inversion, P(t + 1) = P(t) d / (t + 1), the lanes of the wave in
+// lock-step: a step is taken only while some pixel of some lane is still above its running sum (one scalar branch per step).
+// P(X > 1) < 3 % at d = 1/4, so a wave typically leaves after two or three of the seven steps that cover the uniform's
+// resolution (P(Poisson(1/4) > 7) = 1e-10).  EVERY lane of the wave must call.
+template <int NP>
+__device__ inline void poisson_small(const float (&d)[NP], const uint32_t (&w)[NP], uint32_t (&k)[NP]) {
+    float p[NP], cdf[NP], u[NP];
+#pragma unroll
+    for (int s = 0; s < NP; ++s) {
+        p[s] = __expf(-d[s]);
+        cdf[s] = p[s];
+        u[s] = u01_23(w[s]);
+    }
 #pragma unroll
     for (int t = 0; t < (AO_ABL(4) ? 1 : 7); ++t) {
-        k += u > cdf ? 1u : 0u;
-        p *= dl * (1.0f / (float)(t + 1));
-        cdf += p;
+        bool more = false;
+#pragma unroll
+        for (int s = 0; s < NP; ++s) more = more || u[s] > cdf[s];
+        if (!__any(more)) break;
+        const float rt = 1.0f / (float)(t + 1);
+#pragma unroll
+        for (int s = 0; s < NP; ++s) {
+            k[s] += u[s] > cdf[s] ? 1u : 0u;
+            p[s] *= d[s] * rt;
+            cdf[s] += p[s];
+        }
     }
-    return (float)k;
+}
+
+// Poisson(v[s]), 0 <= v[s] < lmax of the table `tab` points to (LDS or global), for the four pixels of a quad.  wf, wr, wc: the
+// quad's three draws (wc is only looked at where v[s] >= 32).  EVERY lane of the wave must call.
+__device__ inline void poisson_alias4(const float (&v)[4], const uint32_t (&wf)[4], const uint32_t (&wr)[4], const uint32_t (&wc)[4],
+                                      const uint32_t* __restrict__ tab, float (&out)[4]) {
+    uint32_t k[4];
+    float d[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const AliasParts a = alias_parts(v[s]);
+        d[s] = a.d;
+        k[s] = alias_draw(tab, a.fine_row, wf[s]) + alias_draw(tab, a.coarse_row, wc[s]);
+    }
+    poisson_small<4>(d, wr, k);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) out[s] = (float)k[s];
 }
 #endif
 

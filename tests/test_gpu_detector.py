@@ -163,3 +163,4 @@ def test_fused_step_kernel_and_separate_kernels_draw_the_same_noise(photon_only)
     if not photon_only:
         assert fa[0, 0, :6, :6].std() > 0     # corner lenslet (not valid, no light): dark + read-out noise
     assert np.abs(oa - ob).max() < 0.05 * np.abs(ob).max() + 1e-3
+

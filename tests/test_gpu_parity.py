@@ -37,7 +37,7 @@ F64_SAME_OPERATOR_TOL = dict(obs=1e-12, reward_rel=1e-11, strehl=1e-13, rms_nm=1
 F64_TOL_BY_CASE = {
     "c2_sh": dict(obs=1.1e-07, signal=1.6e-05, strehl=7.0e-10, rms_nm=1.1e-06, opd_m=3.7e-13, frame_rel=3.1e-07, screen=1.2e-06, host_A=4.0e-10),
     "c3_pyr": dict(obs=3.3e-09, signal=9.6e-07, strehl=1.0e-10, rms_nm=2.5e-08, opd_m=9.5e-14, frame_rel=5.2e-08, screen=1.9e-05, host_A=5.1e-09),
-    "c3_pyr_mod3": dict(obs=3.3e-08, signal=9.6e-06, strehl=1.0e-09, rms_nm=2.5e-07, opd_m=9.5e-13, frame_rel=5.2e-07, screen=1.9e-05, host_A=5.1e-09),
+    "c3_pyr_mod3": dict(obs=3.3e-09, signal=9.6e-07, strehl=1.0e-10, rms_nm=2.5e-08, opd_m=9.5e-14, frame_rel=5.2e-08, screen=1.9e-05, host_A=5.1e-09),
     "c5_mcao": dict(obs=5.0e-08, signal=1.2e-06, strehl=1.0e-10, rms_nm=5.6e-08, opd_m=4.0e-14, frame_rel=4.4e-08, screen=3.2e-06, host_A=4.0e-10),
     "papyrus_pyr": dict(obs=2.8e-06, signal=2.0e-04, strehl=1.5e-06, rms_nm=4.3e-04, opd_m=5.5e-12, frame_rel=1.6e-05, screen=3.9e-06, host_A=5.6e-09),
     "small_sh": dict(obs=3.4e-07, signal=6.6e-06, strehl=3.4e-08, rms_nm=6.3e-05, opd_m=6.2e-13, frame_rel=5.1e-07, screen=1.5e-06, host_A=1.0e-11),
