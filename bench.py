@@ -426,6 +426,7 @@ def bench_config(name, args, torch, timer, rank=0, world=1):
         out["mean_strehl"] = float(env._strehl.mean())
         out["mean_strehl_note"] = "random-weight policy: carries no information about the loop; see integrator_mean_strehl"
         # the same shard under the integrator (gain 0.5), 2 K steps from a fresh episode: a Strehl that says the loop closes
+        env.dm_prev = 0                                         # (the prologue alone keeps the integrator state: here the random policy's)
         obs = start_episode(env)
         env.run_integrator(0, 2 * K)
         out["integrator_mean_strehl"] = float(env._strehl.mean())
@@ -506,7 +507,7 @@ def main():
                     help="WFS camera of the headline: photon (default) = photon (Poisson) noise only, the reference envs' default "
                          "(MAIN/OOPAOEnv/OOPAOEnv.py:379); razor = the Razor env's camera (photon + dark + read-out noise, QE, FWC, "
                          "10-bit ADC: OOPAOEnvRazor.py:243-250, 333); off = the ideal detector of the parity configuration")
-    ap.add_argument("--configs", default="C3,C4,C5", help="comma list of BASELINE configs timed beside the headline (N = 1 only); 'none' skips them")
+    ap.add_argument("--configs", default="C3,C3M,C4,C5", help="comma list of BASELINE configs timed beside the headline (N = 1 only); 'none' skips them")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline + roofline only (profiling runs)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
