@@ -438,6 +438,236 @@ __global__ void __launch_bounds__(256) k_phase_mfma(const KArgs<float> a) {
     }
 }
 
+// The same kernel with every global access a 16-byte one (R a multiple of 4: every BASELINE geometry).  The operands of the DM
+// product are swapped -- gx as A, the Gy C row as B -- so that the matrix cores' output layout gives a lane FOUR CONSECUTIVE pixels
+// of ONE row (the lane -> pixel map of the fused step kernel's stage A): the layer tile is staged with 3 float4 loads per lane
+// instead of 10 dword loads, its taps are read as float4 from LDS, the pupil flags of 4 pixels are one load, the phase (and OPD)
+// rows are written as float4 -- the vector-memory path takes ~16 cycles per wave-instruction whatever its width.  Same arithmetic
+// per pixel (the same taps in the same order, the same k order of the product): results are bit-identical to k_phase_mfma.
+__global__ void __launch_bounds__(256) k_phase_mfma4(const KArgs<float> a) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int R = a.R, nA = a.n_act;
+    constexpr int TX = kTXmax, MW = TX + 4;
+    const int nAp = (nA + 3) & ~3, SS = nAp + 1;             // K padded to 4, s1 row stride odd (bank spread)
+    const bool rows_given = a.pb.s1a != nullptr;             // Gy C already in HBM (k_dm_rows): no command image, no s1 here
+    float* cimg = reinterpret_cast<float*>(lds_raw);         // [nA][nA]
+    float* s1 = cimg + nA * nA;                              // [16][SS]
+    float* mapt = rows_given ? cimg : s1 + kTY * SS;         // [kTY + 3][MW]
+    __shared__ double red[4][4];
+
+    const int e = blockIdx.z;
+    const int y0 = blockIdx.y * kTY, tye = min(kTY, R - y0);      // a workgroup takes the whole 16-row band, 128 columns at a time
+    const int tid = threadIdx.x, lx = tid & 63, ly = tid >> 6;      // ly = wave
+    const int lc = lx & 15, lq = lx >> 4;                            // MFMA lane decomposition
+    const size_t pix0 = (size_t)e * R * R;
+
+    if (blockIdx.y == 0 && tid == 0 && a.pa.store_phase) a.pb.wfs_max[e] = 0.f;
+
+    if (rows_given) {
+    } else if (a.pb.coefs_img) {
+        for (int i = tid; i < kTY * SS; i += 256) s1[i] = 0.f;
+        // batches of 8 independent loads per lane (a load-then-store loop pays one memory latency per iteration)
+        const float* ci = a.pb.coefs_img + (size_t)e * nA * nA;
+        for (int i0 = tid; i0 < nA * nA; i0 += 8 * 256) {
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = ci[i0 + 256 * q < nA * nA ? i0 + 256 * q : i0];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) if (i0 + 256 * q < nA * nA) cimg[i0 + 256 * q] = v[q];
+        }
+    } else {
+        for (int i = tid; i < kTY * SS; i += 256) s1[i] = 0.f;
+        for (int i = tid; i < nA * nA; i += 256) cimg[i] = 0.f;
+        __syncthreads();
+        const float* cf = a.pb.coefs + (size_t)e * a.n_valid_act;
+        for (int k = tid; k < a.n_valid_act; k += 256) cimg[a.pb.act_idx[k]] = cf[k];
+    }
+    __syncthreads();
+    // s1[y][ix] = sum_iy gy[y0 + y][iy] C[iy][ix] on the matrix cores: 16 x 16 output tiles over the command columns,
+    // wave w takes the tiles w, w + 4, ...; the A operands (the tile's 16 rows of gy) are the same for every column tile
+    // and are loaded once, all loads in flight together.  (As a per-output dot product through LDS this was 2/3 of the
+    // kernel at 81 actuators across: a chain of nA LDS latencies per output.)
+    if (!rows_given && !(a.ablate & 1)) {
+        if (nAp <= 32) s1_tiles_mfma<8>(a.pb.gya, a.pb.ga_stride, cimg, s1, y0, R, nA, nAp, SS, lc, lq, ly);
+        else s1_tiles_mfma<32>(a.pb.gya, a.pb.ga_stride, cimg, s1, y0, R, nA, nAp, SS, lc, lq, ly);
+    }
+
+    double s_atm = 0.0, q_atm = 0.0, s_res = 0.0, q_res = 0.0;
+    // (Gy C)[y0 + i][k] of the band from the operand-layout rows k_dm_rows wrote, ONCE for all its column chunks (as separate
+    // 16 x 128 tile workgroups every chunk re-read them: a quarter of the kernel's HBM traffic at 81 actuators across):
+    // ga_stride / 4 16-byte loads per lane (<= 8: n_act <= 128), all in flight together
+    constexpr int NQ = 8;
+    f32x4 aq[NQ];
+    const int nq = a.pb.ga_stride / 4;
+    if (rows_given && !(a.ablate & 4)) {
+        const int Rp = (R + 127) & ~127;
+        const f32x4* asrc = reinterpret_cast<const f32x4*>(a.pb.s1a) + ((size_t)e * (Rp >> 4) + (y0 >> 4)) * nq * 64 + lx;
+#pragma unroll
+        for (int q4 = 0; q4 < NQ; ++q4) aq[q4] = asrc[q4 < nq ? 64 * q4 : 0];
+    }
+    for (int xb = 0; xb < (R + TX - 1) / TX; ++xb) {
+    const int x0 = xb * TX, txe = min(TX, R - x0);
+    // lane's pixels: sub-tile tt (x = 16 (2 ly + tt) + lc), rows y = 4 lq + r
+    float sup[2][4];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sup[tt][r] = 0.f;
+
+    if (a.pa.update_atm && !(a.ablate & 2)) {
+        for (int l = 0; l < a.pa.n_layer; ++l) {
+            const LayerTaps& tp = layer_taps(a.pa, l, e);
+            const int S = a.pa.S_l[l], foot = a.pa.foot_l[l];       // the layer's own grid (fov != 0: it grows with the altitude)
+            const float* map = static_cast<const float*>(a.pa.screen[l]) + (size_t)e * S * S;
+            const int r0 = y0 + foot + tp.dy - 1, c0 = x0 + foot + tp.dx - 1;
+            __syncthreads();                                  // the previous layer's tile is no longer read
+            {
+                // tile element (r, c) = map[r0 + r][c0 + c], staged as rows of MW / 4 float4 (the map rows are only 4-byte aligned)
+                constexpr int MW4 = MW / 4, NV4 = ((kTY + 3) * MW4 + 255) / 256;     // 3 independent 16-byte loads in flight per lane
+                f32x4 v[NV4];
+#pragma unroll
+                for (int k = 0; k < NV4; ++k) {
+                    const int idx = tid + 256 * k;
+                    const int r = idx / MW4, c = 4 * (idx - r * MW4);
+                    const int rr = r0 + r, cc = c0 + c;
+                    const bool need = idx < (kTY + 3) * MW4 && r < tye + 3 && c < txe + 3 && rr >= 0 && rr < S && cc >= 0 && cc < S;
+                    int pr = rr + tp.oy, pc = cc + tp.ox;           // torus: physical = (logical + origin) mod S
+                    pr = pr >= S ? pr - S : pr;
+                    pc = pc >= S ? pc - S : pc;
+                    const bool ok = need && cc + 3 < S && pc + 3 < S;        // the 4 columns are contiguous in memory
+                    f32x4 t;
+                    __builtin_memcpy(&t, map + (ok ? (size_t)pr * S + pc : 0), 16);
+                    v[k] = ok ? t : f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (need && !ok) {
+                        // a float4 that straddles the wrap of the torus or the edge of the screen: element by element
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) {
+                            int pd = pc + d;
+                            pd = pd >= S ? pd - S : pd;
+                            if (cc + d < S) v[k][d] = map[(size_t)pr * S + pd];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < NV4; ++k) {
+                    const int idx = tid + 256 * k;
+                    if (idx < (kTY + 3) * MW4) *reinterpret_cast<f32x4*>(mapt + 4 * idx) = v[k];
+                }
+            }
+            __syncthreads();
+            const float wx0 = (float)tp.wx[0], wx1 = (float)tp.wx[1], wx2 = (float)tp.wx[2], wx3 = (float)tp.wx[3];
+            const float wy0 = (float)tp.wy[0], wy1 = (float)tp.wy[1], wy2 = (float)tp.wy[2], wy3 = (float)tp.wy[3];
+            const float* mm = static_cast<const float*>(a.pa.minmax[l]) + 2 * e;
+            const float lo = mm[0], hi = mm[1], wl = (float)tp.weight;
+            const bool zero_outside = (lo > 0.f || hi < 0.f);
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const int xt = 16 * (2 * ly + tt) + 4 * lq;     // tile column of the first tap of the lane's first pixel
+                // the 4 rows x 8 columns of taps (7 used) as 16-byte LDS reads; horizontal pass per row, then vertical
+                float h[4][4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float* m = mapt + (lc + q) * MW + xt;
+                    const f32x4 m0 = *reinterpret_cast<const f32x4*>(m), m1 = *reinterpret_cast<const f32x4*>(m + 4);
+                    const float t[7] = {m0[0], m0[1], m0[2], m0[3], m1[0], m1[1], m1[2]};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h[q][r] = ((wx0 * t[r] + wx1 * t[r + 1]) + wx2 * t[r + 2]) + wx3 * t[r + 3];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = ((wy0 * h[0][r] + wy1 * h[1][r]) + wy2 * h[2][r]) + wy3 * h[3][r];
+                    if (!(zero_outside && v == 0.f)) v = v < lo ? lo : (v > hi ? hi : v);
+                    sup[tt][r] += v * wl;
+                }
+            }
+        }
+    }
+    if (xb == 0) __syncthreads();                                 // s1 complete
+
+    // the pupil flags of the lane's 2 x 4 pixels: one 4-byte load each (x and R are multiples of 4)
+    bool pup[2][4];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const int xl = 16 * (2 * ly + tt) + 4 * lq, y = lc;
+        const bool okp = xl < txe && y < tye;
+        uint32_t t4 = 0x01010101u;
+        if (!(a.ablate & 64)) __builtin_memcpy(&t4, a.pb.pupil + (okp ? (size_t)(y0 + y) * R + (x0 + xl) : 0), 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pup[tt][r] = okp && ((t4 >> (8 * r)) & 0xffu) != 0;
+    }
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const int xl = 16 * (2 * ly + tt) + 4 * lq;               // the lane's 4 consecutive columns; its row is lc
+        f32x4 dmv = {0.f, 0.f, 0.f, 0.f};
+        const float* ap = s1 + lc * SS + lq;                      // B[k = lane >> 4][j = lane & 15 -> row]      (LDS)
+        // D[x][y] = sum_k gx[x][k] (Gy C)[y][k]: gx is the A operand (i = lane & 15 -> column of the 16-column sub-tile) and the
+        // Gy C row the B operand, so that the matrix cores' output layout (rows 4 (lane >> 4) + r, column lane & 15) hands a
+        // lane FOUR CONSECUTIVE pixels of ONE row: every global access below is a 16-byte one
+        const f32x4* bsrc = reinterpret_cast<const f32x4*>(a.pb.gxa) + (size_t)((x0 >> 4) + 2 * ly + tt) * nq * 64 + lx;
+        if (rows_given) {
+            if (!(a.ablate & 4)) {
+            f32x4 bq[NQ];
+#pragma unroll
+            for (int q4 = 0; q4 < NQ; ++q4) bq[q4] = bsrc[q4 < nq ? 64 * q4 : 0];
+#pragma unroll
+            for (int q4 = 0; q4 < NQ; ++q4)
+                if (16 * q4 < nAp) {                              // uniform
+#pragma unroll
+                    for (int d = 0; d < 4; ++d)
+                        if (16 * q4 + 4 * d < nAp) dmv = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[q4][d], aq[q4][d], dmv, 0, 0, 0);
+                }
+            }
+        } else if (!(a.ablate & 4))
+        for (int kb = 0; kb < nAp; kb += 32) {                    // 8 k steps = 2 loads per batch
+            const f32x4 b0 = bsrc[64 * (kb / 16)], b1 = bsrc[64 * (kb / 16 + 1 < nq ? kb / 16 + 1 : kb / 16)];
+            const float bv[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (kb + 4 * j < nAp) dmv = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[j], ap[kb + 4 * j], dmv, 0, 0, 0);
+        }
+        if (xl < txe && lc < tye) {
+            const size_t q = (size_t)(y0 + lc) * R + (x0 + xl);
+            f32x4 atm, phi;
+            if (!a.pa.update_atm) atm = *reinterpret_cast<const f32x4*>(a.pb.opd_atm + pix0 + q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (a.pa.update_atm) atm[r] = sup[tt][r] * a.atm_scale;
+                const bool in = (a.ablate & 16) ? true : pup[tt][r];
+                const float res = in ? (atm[r] + dmv[r]) : 0.f;
+                phi[r] = res * a.src_scale;
+                if (in && !(a.ablate & 32)) {
+                    const double da = (double)atm[r], dr = (double)res;
+                    s_atm += da;
+                    q_atm += da * da;
+                    s_res += dr;
+                    q_res += dr * dr;
+                }
+            }
+            if (a.pa.update_atm && a.pa.store_atm) *reinterpret_cast<f32x4*>(a.pb.opd_atm + pix0 + q) = atm;
+            if (a.pa.store_phase && !(a.ablate & 8)) *reinterpret_cast<f32x4*>(a.pb.phase + pix0 + q) = phi;
+        }
+    }
+    }
+    s_atm = wave_sum(s_atm);
+    q_atm = wave_sum(q_atm);
+    s_res = wave_sum(s_res);
+    q_res = wave_sum(q_res);
+    if (lx == 0) {
+        red[0][ly] = s_atm;
+        red[1][ly] = q_atm;
+        red[2][ly] = s_res;
+        red[3][ly] = q_res;
+    }
+    __syncthreads();
+    if (tid < 4 && a.pa.store_phase) {
+        // (the telemetry buffer has one slot per 16 x 128 tile, phase_tiles(): the band's sums go to its first slot)
+        const int gx = (R + TX - 1) / TX, n_tiles = gx * gridDim.y;
+        double* pp = a.pb.part + ((size_t)e * n_tiles + (size_t)blockIdx.y * gx) * 4;
+        pp[tid] = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
+        for (int t = 1; t < gx; ++t) pp[4 * t + tid] = 0.0;
+    }
+}
+
 template <typename T>
 int launch_phase_mfma(const KArgs<T>&, int, hipStream_t) { return -1; }
 template <>
@@ -450,7 +680,13 @@ int launch_phase_mfma<float>(const KArgs<float>& a, int n_env, hipStream_t st) {
         AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_phase_mfma), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds));
     dim3 grid(cdiv(a.R, TX), cdiv(a.R, kTY), n_env);
-    hipLaunchKernelGGL(k_phase_mfma, grid, dim3(256), lds, st, a);
+    if (a.R % 4 == 0 && !(a.ablate & 256)) {
+        if (lds > 64 * 1024)
+            AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_phase_mfma4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_phase_mfma4, dim3(1, grid.y, grid.z), dim3(256), lds, st, a);      // one workgroup per 16-row band
+    } else {
+        hipLaunchKernelGGL(k_phase_mfma, grid, dim3(256), lds, st, a);
+    }
     AO_HIP(hipGetLastError());
     return 0;
 }

@@ -136,6 +136,10 @@ __global__ void __launch_bounds__(128, 2) k_sh_spots_p6(const T* __restrict__ ph
     const T ctab = cos_table_lane<T>();
     T mx = 0;
     for (int j0 = 0; j0 < n_subap; j0 += SPW) {
+        // a strip without a valid lenslet (the corners of the lenslet array: 7 % of the strips of an 80 x 80 array) is all zeros
+        const int j = j0 + jl;
+        const bool ok = row_ok && lane < SPW * HP && j < n_subap && valid2d[i * n_subap + j] != 0;
+        const bool lit = __any(ok);                                    // (wave-uniform; the barriers below stay unconditional)
         // ---- stage 0: strip of phase -> E0 in LDS (all loads of the lane issued before the first use) ---------
         constexpr int NP = (P * W + kWave - 1) / kWave;                 // 12 pixels per lane
         T phv[NP], amv[NP];
@@ -146,31 +150,31 @@ __global__ void __launch_bounds__(128, 2) k_sh_spots_p6(const T* __restrict__ ph
             const int col = j0 * P + c;
             phv[k] = (T)0;
             amv[k] = (T)0;
-            if (row_ok && t < P * W && col < R) {
+            if (lit && t < P * W && col < R) {
                 const int pix = (i * P + b) * R + col;
                 amv[k] = sc.amp[pix];
                 phv[k] = ph[pix];
             }
         }
+        if (lit) {
 #pragma unroll
-        for (int k = 0; k < NP; ++k) {
-            const int t = lane + k * kWave;
-            if (t < P * W) {
-                const int b = t / W, c = t - b * W;
-                T sn, cs;
-                if (FAST_TRIG) sincos_fast(phv[k], &sn, &cs); else sincos_t<T>(phv[k], &sn, &cs);
-                const int jj = c / P, a = c - jj * P;
-                Ew[jj * EST + a * P + b] = {amv[k] * cs, amv[k] * sn};
+            for (int k = 0; k < NP; ++k) {
+                const int t = lane + k * kWave;
+                if (t < P * W) {
+                    const int b = t / W, c = t - b * W;
+                    T sn, cs;
+                    if (FAST_TRIG) sincos_fast(phv[k], &sn, &cs); else sincos_t<T>(phv[k], &sn, &cs);
+                    const int jj = c / P, a = c - jj * P;
+                    Ew[jj * EST + a * P + b] = {amv[k] * cs, amv[k] * sn};
+                }
             }
         }
         __syncthreads();
 
-        const int j = j0 + jl;
-        const bool ok = row_ok && lane < SPW * HP && j < n_subap && valid2d[i * n_subap + j] != 0;
         T Ia[P], Ib[P];
 #pragma unroll
         for (int u = 0; u < P; ++u) Ia[u] = Ib[u] = (T)0;
-        if (row_ok)                                                    // wave-uniform: the twiddle shuffles need every lane
+        if (lit)                                                       // wave-uniform: the twiddle shuffles need every lane
             lenslet_spots<T>(Ew + (lane < SPW * HP ? jl : 0) * EST, q, ctab, Ia, Ib);
         if (!ok) {
 #pragma unroll

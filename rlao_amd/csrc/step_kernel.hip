@@ -165,6 +165,7 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
     if (tid < n_sub * n_sub) slot_s[tid] = slot_v;
     for (int i = tid + 1024; i < n_sub * n_sub; i += 1024) slot_s[i] = a.slot_of[i];
     lds_barrier();
+    AO_STAMP(24);
     if (has_act) cimg[act_px] = act_c;
     float breg[2][KS];
 #pragma unroll
@@ -177,6 +178,7 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
 
     // ---- s1[y][ix] = sum_iy gy[y][iy] C[iy][ix] for every row, on the matrix cores: 8 x 2 tiles of 16 x 16, one per wave ---
     lds_barrier();                                             // cimg complete
+    AO_STAMP(25);
     {
         const int ix = 16 * ct + lc;
         float av[KS], bv[KS];
@@ -199,6 +201,7 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
         }
     }
 
+    AO_STAMP(26);
     // ---- deferred ring scatter: map_full[outerMask] = X of a layer that crossed a pixel this step ----------------------------
     // The ring values are the fixed-order sum of the GEMM's split-K slabs, written through the torus origin.  This
     // workgroup is the only reader of this env's map in this launch, and its vector L1 holds no line of it yet (no load of
@@ -240,6 +243,7 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
         }
     }
 
+    AO_STAMP(27);
     // ---- range of every layer's screen (the warp clips to it): read back, or recomputed here after a ring extrusion -------
     __shared__ float lohi[kMaxLayer][2];
     __shared__ float red_lo[16], red_hi[16];

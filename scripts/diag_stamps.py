@@ -22,10 +22,12 @@ names = {0: "start", 1: "p0 sync", 3: "p0 s1 (mfma) + amp loads issued", 4: "p0 
          13: "p1 epilogue done", 14: "E0 sync", 22: "spots (DFT) done", 23: "camera: faint pixels drawn, queue written",
          2: "camera: queue drawn (wave 0)", 15: "camera finished, frame stored", 16: "max sync", 17: "centroid sync",
          19: "tail: t = M s", 20: "tail: o = M2C t, integrator", 21: "tail: obs write + reduce", 18: "tail: scalar finish"}
-idx = [0, 1, 3, 4, 5, 7, 9, 10, 11, 13, 14, 22] + ([23, 6, 8] if CAM != "ideal" else []) + [15, 16, 17, 19, 20, 21, 18]
+idx = [0, 24, 25, 26, 27, 1, 3, 4, 5, 7, 9, 10, 11, 13, 14, 22] + ([23, 6, 8] if CAM != "ideal" else []) + [15, 16, 17, 19, 20, 21, 18]
 names.update({23: "camera: lenslet indices loaded", 6: "camera: own share of the tables landed", 8: "camera: barrier (tables complete)",
               15: "camera drawn, frame stored"})
-names[1] = "prologue + s1 (mfma)"; names[3] = "p0 amp loads issued, sync"; names[9] = "p1 amp loads issued, sync"
+names.update({24: "prologue: loads issued, LDS zeroed, 1st barrier", 25: "command image written, 2nd barrier", 26: "Gy C on the matrix cores, s1 stored",
+              27: "ring scatter (crossing steps) + next Z"})
+names[1] = "screen ranges + barrier before stage A"; names[3] = "p0 amp loads issued, sync"; names[9] = "p1 amp loads issued, sync"
 prev = None
 for i in idx:
     d = "" if prev is None else f"{np.median(st[:, i] - st[:, prev]):9.0f} ticks"

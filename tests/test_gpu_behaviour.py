@@ -550,3 +550,34 @@ def test_tensors_handed_out_by_step_survive_the_next_episode():
         assert torch.equal(t, k)
     assert not torch.equal(o2, obs) and o2.data_ptr() != obs.data_ptr()
     env.close()
+
+
+@pytest.mark.parametrize("coefs_image", [0, 1])
+def test_phase_kernel_with_16_byte_accesses_is_bit_identical(coefs_image):
+    """k_phase_mfma4 (lane = one row, four consecutive pixels: float4 tile loads, taps, pupil flags and phase stores) against
+    k_phase_mfma (dword accesses; forced through the diagnostic switch 99 = 256): the same taps in the same order and the same k order
+    of the DM product, so every output bit agrees -- three layers with winds that move the torus origins (float4s that straddle the
+    wrap), both forms of the Gy C operand (computed in the kernel / handed over by k_dm_rows)."""
+    import torch
+    from rlao_amd import _lib as L
+    from rlao_amd.env import BatchedAOEnv
+    geo = dict(SMALL, windSpeed=[40.0, 25.0, 33.0], windDirection=[72.0, 200.0, 310.0], fractionalR0=[0.6, 0.3, 0.1],
+               altitude=[0.0, 0.0, 0.0])
+    outs = []
+    for old in (0, 1):
+        env = BatchedAOEnv(n_envs=3, device=0, dtype="f32")
+        env.set_params(geo, camera="ideal", wfs_type="shackhartmann", gainCL=0.4)
+        L.check(env._shard.lib.aoenv_set_option(env._shard.h, L.OPT_FUSED_STEP, 0))
+        L.check(env._shard.lib.aoenv_set_option(env._shard.h, L.OPT_COEFS_IMAGE, coefs_image))
+        if old:
+            L.check(env._shard.lib.aoenv_set_option(env._shard.h, 99, 256))
+        rec = _run(env, 12, 5, gain=0.4)
+        phase = env._shard.download(L.B_PHASE, (3, env.R, env.R))
+        opd = env._shard.download(L.B_OPD_ATM, (3, env.R, env.R))
+        outs.append((rec, phase, opd, env.total[:12].copy(), env.residual[:12].copy()))
+        env.close()
+    (ra, pa, oa, ta, sa), (rb, pb, ob, tb, sb) = outs
+    for x, y in zip(ra, rb):
+        assert all(torch.equal(p, q) for p, q in zip(x, y))
+    assert np.array_equal(pa, pb) and np.array_equal(oa, ob) and np.array_equal(ta, tb) and np.array_equal(sa, sb)
+    assert np.abs(pa).max() > 0
