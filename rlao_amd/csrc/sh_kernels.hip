@@ -260,6 +260,17 @@ __global__ void __launch_bounds__(256) k_sh_centroid(const T* __restrict__ frame
         for (int u = sub; u < p; u += 8) {
             const T* row = fr + (size_t)(i * p + u) * R + j * p;
             T rs = 0, rm = 0;
+            if (p == 6) {                                          // every BASELINE geometry: the row's 6 pixels requested together
+                T xv[6];                                           // (a loop over a run-time p is a chain of 6 memory latencies)
+#pragma unroll
+                for (int v = 0; v < 6; ++v) xv[v] = row[v];
+#pragma unroll
+                for (int v = 0; v < 6; ++v) {
+                    const T x = xv[v] < cut ? (T)0 : xv[v];
+                    rs += x;
+                    rm += x * (T)v;
+                }
+            } else
             for (int v = 0; v < p; ++v) {
                 T x = row[v];
                 x = x < cut ? (T)0 : x;
@@ -333,6 +344,17 @@ __global__ void __launch_bounds__(1024) k_sh_tail(const T* __restrict__ frame, c
         for (int u = half; u < p; u += 2) {
             const T* row = fr + (size_t)(i * p + u) * R + j * p;
             T rs = 0, rm = 0;
+            if (p == 6) {                                          // every BASELINE geometry: the row's 6 pixels requested together
+                T xv[6];                                           // (a loop over a run-time p is a chain of 6 memory latencies)
+#pragma unroll
+                for (int v = 0; v < 6; ++v) xv[v] = row[v];
+#pragma unroll
+                for (int v = 0; v < 6; ++v) {
+                    const T x = xv[v] < cut ? (T)0 : xv[v];
+                    rs += x;
+                    rm += x * (T)v;
+                }
+            } else
             for (int v = 0; v < p; ++v) {
                 T x = row[v];
                 x = x < cut ? (T)0 : x;

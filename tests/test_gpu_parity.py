@@ -29,6 +29,9 @@ F32_TOL = dict(obs=4.5e-5, reward_rel=1e-4, strehl=6e-6, rms_nm=4.5e-3, signal=6
 #   the device arithmetic against NumPy's -- re-ordering noise.  Measured maxima: obs 5e-14, signal 1.5e-13, strehl 2e-15,
 #   rms 1e-12 nm, opd 1e-20 m, frame 1e-14, screen 5e-14.
 F64_SAME_OPERATOR_TOL = dict(obs=1e-12, reward_rel=1e-11, strehl=1e-13, rms_nm=1e-11, signal=2e-12, opd_m=1e-18, frame_rel=1e-13, screen=1e-12)
+#   ... and at the FULL size of the headline geometry (c2_sh with tests/golden/c2_sh_AB.npz: 20 steps, slopes up to 48, 632 of them):
+#   measured maxima obs 6.7e-13, signal 3.5e-12, strehl 1.6e-16, rms 6.8e-13 nm, opd 4.7e-21 m, frame 4.2e-15, screen 1.2e-13
+F64_SAME_OPERATOR_TOL_FULL = dict(obs=7e-12, reward_rel=1e-11, strehl=2e-15, rms_nm=7e-12, signal=4e-11, opd_m=5e-20, frame_rel=5e-14, screen=2e-12)
 #   float64 shards with the operators recomputed on the test host: A = ZXt^T pinv(ZZt) goes through the pseudo-inverse of a covariance
 #   matrix of condition ~1e9 and differs between CPUs / LAPACK builds (host_A = max |A_host - A_golden| measured on the GPU box:
 #   1e-12 .. 6e-9); every ring extrusion feeds that difference into the screens and the closed loop carries it.  This -- not the
@@ -42,7 +45,7 @@ F64_TOL_BY_CASE = {
     "papyrus_pyr": dict(obs=2.8e-06, signal=2.0e-04, strehl=1.5e-06, rms_nm=4.3e-04, opd_m=5.5e-12, frame_rel=1.6e-05, screen=3.9e-06, host_A=5.6e-09),
     "small_sh": dict(obs=3.4e-07, signal=6.6e-06, strehl=3.4e-08, rms_nm=6.3e-05, opd_m=6.2e-13, frame_rel=5.1e-07, screen=1.5e-06, host_A=1.0e-11),
     "tiny_3layer": dict(obs=4.9e-09, signal=7.7e-08, strehl=2.7e-09, rms_nm=1.4e-06, opd_m=1.5e-14, frame_rel=2.0e-08, screen=1.5e-07, host_A=1.7e-12),
-    "tiny_3layer_fov1": dict(obs=4.9e-08, signal=7.7e-07, strehl=2.7e-08, rms_nm=1.4e-05, opd_m=1.5e-13, frame_rel=2.0e-07, screen=1.5e-06, host_A=1.7e-12),
+    "tiny_3layer_fov1": dict(obs=2.6e-09, signal=4.3e-08, strehl=7.0e-10, rms_nm=9.3e-07, opd_m=5.0e-15, frame_rel=8.2e-09, screen=8.0e-08, host_A=1.7e-12),
     "tiny_fastwind": dict(obs=4.8e-08, signal=7.4e-07, strehl=3.9e-09, rms_nm=1.1e-05, opd_m=9.8e-14, frame_rel=1.3e-07, screen=1.1e-07, host_A=1.7e-12),
     "tiny_pyr": dict(obs=6.1e-09, signal=8.8e-07, strehl=6.4e-09, rms_nm=1.1e-06, opd_m=3.3e-14, frame_rel=5.7e-08, screen=9.9e-08, host_A=1.7e-12),
     "tiny_pyr_mod": dict(obs=4.1e-09, signal=2.5e-07, strehl=1.2e-09, rms_nm=2.1e-07, opd_m=9.1e-15, frame_rel=9.8e-09, screen=8.0e-08, host_A=1.7e-12),
@@ -218,7 +221,7 @@ def test_golden_replay(name, dtype, golden_dir):
             np.testing.assert_allclose(np.linalg.norm(env.imat), float(g["imat_fro"]), rtol=1e-9)
             np.testing.assert_allclose(env.imat @ g["m2c"], g["modal_imat"], atol=2e-9 * np.abs(g["modal_imat"]).max())
             np.testing.assert_allclose(env.modal_CM, g["modal_cm"], atol=1e-7 * np.abs(g["modal_cm"]).max())
-        _replay(env, g, F64_SAME_OPERATOR_TOL if inject else (_f64_tol(name, float(dA)) if dtype == "f64" else F32_TOL), seeds, label=label)
+        _replay(env, g, (F64_SAME_OPERATOR_TOL if "A" in g else F64_SAME_OPERATOR_TOL_FULL) if inject else (_f64_tol(name, float(dA)) if dtype == "f64" else F32_TOL), seeds, label=label)
     finally:
         env.close()
 
