@@ -19,7 +19,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, n_envs, camera = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 note = sys.argv[4] if len(sys.argv) > 4 else ""
 OUT = os.path.join(REPO, "gpurun_out")
-SHORT = {"k_env_step_sh6": "env_step", "k_ring_prepare": "ring_prepare", "k_gemm_nt_mfma": "gemm_mfma", "k_phase_mfma": "phase",
+SHORT = {"k_env_step_sh6": "env_step", "k_ring_prepare": "ring_prepare", "k_gemm_nt_mfma": "gemm_mfma", "k_phase_mfma": "phase", "k_phase_mfma4": "phase",
          "k_sh_spots_p6": "sh_spots", "k_sh_centroid": "sh_centroid", "k_sh_tail": "sh_tail", "k_recon_finish": "recon_finish",
          "k_pyr_rows": "pyr_rows", "k_pyr_cols": "pyr_cols", "k_pyr_rows_inv": "pyr_rows_inv", "k_pyr_slopes": "pyr_slopes",
          "k_detector": "detector", "k_detector_sh6": "detector_sh6", "k_dm_rows": "dm_rows", "k_scatter_minmax": "ring_scatter",
