@@ -329,6 +329,9 @@ int launch_pyramid_n(const PyrArgs<T>& base, int n_theta, int chunk, hipStream_t
 // SIMD instead of 4: measured 5.7 -> 7.4 ms per step at 1024 envs) or spill.
 template <typename T>
 int launch_pyramid(const PyrArgs<T>& base, int n_theta, int chunk, hipStream_t st) {
+    if constexpr (sizeof(T) == 4) {
+        if (pyramid528_supported(base)) return launch_pyramid528(base, n_theta, chunk, st);
+    }
     if (sizeof(T) == 4 && base.N == 528 && base.plan.n_fac == 3) return launch_pyramid_n<T, 528, 0>(base, n_theta, chunk, st);
     if (sizeof(T) == 4 && base.N == 288 && base.plan.n_fac == 4) return launch_pyramid_n<T, 288, 288>(base, n_theta, chunk, st);
     return launch_pyramid_n<T, 0, 0>(base, n_theta, chunk, st);

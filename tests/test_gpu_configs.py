@@ -291,3 +291,35 @@ def test_c2_geometry_1000_envs_ragged_shard():
     for x, y in zip(big, small):
         assert all(torch.equal(p[999], q[0]) for p, q in zip(x, y))
     assert float(big[-1][3].std()) > 0
+
+
+@pytest.mark.parametrize("modulation", [0.0, 3.0])
+def test_c3_pyramid_528_register_passes_match_the_stockham_passes(modulation):
+    """nRes = 528 in float32 runs the 24 x 22 register-resident transform (pyr528_kernels.hip); diagnostic option 99 bit 512
+    puts the same shard back on the Stockham passes of pyr_kernels.hip (what float64 and every other length run).  Same field,
+    same mask, different order of the float32 butterflies: frames agree to float32 rounding of the brightest pixel."""
+    import torch
+    from rlao_amd import _lib as L
+    from rlao_amd.env import BatchedAOEnv
+    env = BatchedAOEnv(n_envs=4, device=0, dtype="f32", env_seed_stride=1)
+    try:
+        env.set_params(dict(C3, modulation=modulation), camera="ideal", wfs_type="pyramid")
+        env.generate_new_phase_screen(5)
+        env.dm.coefs = 0
+        frames, signals = [], []
+        for generic in (0, 512, 0):
+            L.check(env._shard.lib.aoenv_set_option(env._shard.h, 99, generic))
+            env.measure()
+            frames.append(env._shard.download(L.B_FRAME, (4, env.cam_res, env.cam_res)).astype(np.float64))
+            signals.append(env._shard.download(L.B_SIGNAL, (4, env.nSignal)).astype(np.float64))
+        torch.cuda.synchronize()
+        assert np.array_equal(frames[0], frames[2]) and np.array_equal(signals[0], signals[2])      # bitwise reruns
+        assert not np.array_equal(frames[0], frames[1])                                            # the option did switch paths
+        peak = frames[1].max()
+        assert peak > 0 and np.isfinite(frames[0]).all()
+        err = np.abs(frames[0] - frames[1]).max() / peak
+        serr = np.abs(signals[0] - signals[1]).max() / np.abs(signals[1]).max()
+        print(f"528 passes vs Stockham, modulation {modulation}: frame {err:.2e} of the peak, signal {serr:.2e} of the max")
+        assert err < 2e-6 and serr < 2e-5, (err, serr)
+    finally:
+        env.close()
