@@ -325,7 +325,8 @@ struct PyrArgs {
     unsigned magic_seq;    // floor(2^32 / seq_per_block) + 1: i / seq_per_block for i < 2^16 without a division (set by the launchers)
     int phasor_mult;       // the pupil field is multiplied by exp(-i pi m (x + y) / N) on the padded grid: m = N + 1 (Pyramid with a
                            // centred mask, Pyramid.py:294), 1 (science PSF, Telescope.py:316), 0 (none)
-    int generic_fft;       // diagnostic (aoenv_set_option 99, bit 512): the Stockham passes also where pyr528_kernels.hip applies
+    int generic_fft;       // diagnostic (aoenv_set_option 99): bit 512 the Stockham passes also where pyr528_kernels.hip applies, bit 1024
+                           // its column blocks dealt round-robin over the XCDs
 };
 // nRes = 528 in float32: the passes on the register-resident 24 x 22 transform (pyr528_kernels.hip)
 int pyramid528_supported(const PyrArgs<float>& a);

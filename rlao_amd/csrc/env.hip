@@ -538,7 +538,7 @@ int run_wfs(AoEnv* env, hipStream_t st) {
         pa.centering = env->c.pyr_centering;
         pa.phasor_mult = env->c.pyr_centering ? env->c.pyr_n_res + 1 : 0;
         pa.n_env = env->E;
-        pa.generic_fft = (env->debug_ablate & 512) ? 1 : 0;
+        pa.generic_fft = env->debug_ablate & (512 | 1024);
         PyrSlopeArgs<T> sl{};
         sl.frame = env->as<T>(env->frame);
         sl.valid_idx = env->subap_idx;

@@ -203,7 +203,6 @@ template <int KS>
 __device__ inline void s1_tiles_mfma(const float* __restrict__ gya, int ga_stride, const float* cimg, float* s1, int y0, int R,
                                      int nA, int nAp, int SS, int lc, int lq, int wave) {
     float av[KS];
-    const int yrow = y0 + lc;                                // < Rpad128: the table is zero padded beyond R and n_act
     {
         const f32x4* src = reinterpret_cast<const f32x4*>(gya) + (size_t)(y0 >> 4) * (ga_stride >> 2) * 64 + (lq * 16 + lc);
 #pragma unroll

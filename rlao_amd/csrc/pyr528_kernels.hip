@@ -6,15 +6,17 @@
 //
 // A workgroup is 192 lanes = 8 sequences x 24 lanes: "role A" is (sequence, n2 or m1 < 22) -- 176 lanes, the 24-point factor --
 // and "role B" is (sequence, k1 < 24), the 22-point factor.
-//   P1 rows     : role A builds the field of 8 pupil rows (x = 22 n1 + n2 - off), 24-point DFT, twiddle, exchange; role B 22-point
-//                 DFT and stores X[k1 + 24 k2]: 192 contiguous bytes per sequence and store.
-//   P2 columns  : role A loads 8 neighbouring columns of T1 (64 contiguous bytes per row), 24-point DFT, twiddle, exchange; role B
+//   P1 rows     : the field of 8 pupil rows is built in LDS with the lanes along x; role A takes x = 22 n1 + n2 - off from there,
+//                 24-point DFT, twiddle, exchange; role B 22-point DFT and stores X[k1 + 24 k2]: 192 contiguous bytes per sequence
+//                 and store.
+//   P2 columns  : (16 sequences, 384 lanes) role A loads 16 neighbouring columns of T1 (one 128-byte line per row), 24-point DFT, twiddle, exchange; role B
 //                 22-point DFT, fftshift (k2 -> k2 + 11: a renaming) and mask, inverse 22-point DFT, twiddle, exchange; role A
 //                 inverse 24-point DFT and stores T2.  Two exchanges for two transforms.
 //   P3 rows^-1  : role B loads rows of T2, inverse 22-point DFT, twiddle, exchange; role A inverse 24-point DFT, |.|^2, summed over
 //                 the rows of a camera row and the modulation points in LDS, binned to the camera row.
 // LDS layouts are chosen per pass so that the exchange is conflict-free for the lane order that keeps global accesses
 // contiguous (bank rules of ds_write_b64 / ds_read_b64, MI355X_MICROARCH.md; scripts/lds_banks_528.py counts them).
+// Measured at 1024 envs (C3): 410 + 1100 + 520 us against 837 + 2827 + 1583 us for the Stockham passes.
 #include "common.hpp"
 #include "fft.hpp"
 #include "fft528.hpp"
@@ -22,6 +24,22 @@
 namespace ao {
 
 using f528::v2;
+// diagnostic build (-DAO_PYR_STAMPS, scripts/diag_pyr_stamps.py): s_memtime per wave at the phases of the column pass
+#ifdef AO_PYR_STAMPS
+__device__ unsigned long long g_pstamps[32 * 40 * 6 * 8];
+#define AO_PSTAMP(i) do { if ((threadIdx.x & 63) == 0 && blockIdx.y == 0 && blockIdx.z >= 500 && blockIdx.z < 532) \
+    g_pstamps[(((blockIdx.z - 500) * 40 + blockIdx.x) * 6 + (threadIdx.x >> 6)) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int aoenv_debug_pstamps(unsigned long long* h_out) {
+    return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_pstamps), sizeof(unsigned long long) * 32 * 40 * 6 * 8) == hipSuccess ? 0 : 1;
+}
+#else
+#define AO_PSTAMP(i) do { } while (0)
+#endif
+#ifdef AO_PYR_STAMPS
+}  // namespace ao
+extern "C" int aoenv_debug_pyr_occupancy(int* out3);
+namespace ao {
+#endif
 constexpr int kLanes528 = 192, kTws = 23;                         // twiddle table [k1][n2] with rows of 23 (odd: see P2's inverse reads)
 
 // w_528^(k1 n2), k1 < 24, n2 < 22, from the N-entry table of the env (k1 n2 <= 483 < 528)
@@ -33,53 +51,100 @@ __device__ inline void load_tws(v2* __restrict__ tws, const float* __restrict__ 
     }
 }
 
+// sin and cos of a float32 angle: three-term Cody-Waite reduction by pi/2 with fused multiply-adds (exact to float32 rounding
+// for |x| < 3e4 rad: the quotient has 15 bits) and the fdlibm float kernels on |r| <= pi/4; larger angles take the library's
+// routine.  ~30 instructions against ~150 for an inlined sincosf (whose large-argument path is never taken by a wave-front
+// of a few hundred radians); both are within 1-2 ulp.
+__device__ inline void sincos_cw(float x, float* sn, float* cs) {
+    if (fabsf(x) > 30000.f) {
+        sincosf(x, sn, cs);
+        return;
+    }
+    const float k = rintf(x * 0.63661977236758134308f);
+    float r = fmaf(-k, 1.57079637050628662109375f, x);
+    r = fmaf(-k, -4.37113900018624283e-8f, r);
+    r = fmaf(-k, -1.71512449079261335e-15f, r);
+    const float z = r * r;
+    const float ps = fmaf(fmaf(fmaf(2.7183114939898219064e-6f, z, -1.98393348360966317347e-4f), z, 8.3333293858894631756e-3f), z, -0.166666666416265235595f);
+    const float pc = fmaf(fmaf(fmaf(2.43904487962774090654e-5f, z, -1.38867637746099294692e-3f), z, 4.16666233237390631894e-2f), z, -0.499999997251031003120f);
+    const float s = fmaf(r * z, ps, r), c = fmaf(z, pc, 1.f);
+    const int q = (int)k;
+    const float ss = (q & 1) ? c : s, cc = (q & 1) ? s : c;
+    *sn = (q & 2) ? -ss : ss;
+    *cs = ((q + 1) & 2) ? -cc : cc;
+}
+
 // ---- P1: grid = (ceil(R / 8), chunk, E) -----------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kLanes528) k_pyr528_rows(const PyrArgs<float> a) {
     constexpr int N = f528::kN, SEQ = 550, S2 = 25;               // ex[c][n2][k1]: rows of 25 (odd) -> conflict-free writes
-    __shared__ v2 ex[8 * SEQ];
+    __shared__ v2 ex[8 * SEQ];                                    // first the field of the 8 rows: fld[c][x - 22 n1_lo]
     __shared__ v2 tws[24 * kTws];
     const int tid = threadIdx.x, R = a.R, off = a.off;
     load_tws(tws, a.tw, tid);
     const int e = blockIdx.z, th = blockIdx.y, y0 = blockIdx.x * 8;
     const int n1_lo = off / 22, n1_hi = (off + R - 1) / 22;       // the 24-point inputs that can be inside the pupil, for any lane
-    if (tid < 176) {
-        const int c = tid / 22, n2 = tid - 22 * c, row = y0 + c;
+    {
+        // the field on the columns 22 n1_lo .. 22 (n1_hi + 1) of the padded grid, lanes along x (W = a.seq_per_block columns per row)
+        const int W = a.seq_per_block, x_lo = 22 * n1_lo;
         const float* ph = a.phase + (size_t)e * R * R;
         const float* tt = a.tt ? a.tt + (size_t)(a.theta0 + th) * R * R : nullptr;
         const float pi_over_n = (float)(3.14159265358979323846 / N);
-        v2 v[24];
+        // four points per lane and turn: their loads are independent of one another and issued together (one point at a time,
+        // amplitude -> branch -> phase is a chain of two memory latencies per point: 20 us per workgroup)
+        for (int i0 = tid; i0 < 8 * W; i0 += 4 * kLanes528) {
+            float am[4], ang[4];
+            int cc[4], xx[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * kLanes528;
+                cc[u] = fastdiv(i, a.magic_seq);
+                xx[u] = i - cc[u] * W;
+                const int x = x_lo + xx[u] - off, row = y0 + cc[u];
+                const bool in = i < 8 * W && row < R && (unsigned)x < (unsigned)R;
+                const int p = in ? row * R + x : 0;
+                am[u] = in ? a.amp[p] : 0.f;
+                ang[u] = ph[p];
+                if (tt) ang[u] += tt[p];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                v2 f = v2{0.f, 0.f};
+                if (am[u] != 0.f) {
+                    // centred mask: exp(-i pi (N+1)/N (x + y)) on the padded grid, angle reduced mod 2 pi in integers (k_pyr_rows)
+                    const int xg = x_lo + xx[u], row = y0 + cc[u];
+                    const float pang = a.phasor_mult ? pi_over_n * (float)((a.phasor_mult * (xg + row + off)) % (2 * N)) : 0.f;
+                    float sn, co;
+                    sincos_cw(ang[u] - pang, &sn, &co);
+                    f = v2{am[u] * co, am[u] * sn};
+                }
+                if (i0 + u * kLanes528 < 8 * W) ex[cc[u] * SEQ + xx[u]] = f;
+            }
+        }
+    }
+    __syncthreads();
+    const int ca = tid / 22, n2 = tid - 22 * ca;
+    v2 v[24];
+    if (tid < 176) {
 #pragma unroll
         for (int n1 = 0; n1 < 24; ++n1) {
             v[n1] = v2{0.f, 0.f};
-            if (n1 >= n1_lo && n1 <= n1_hi) {
-                const int xg = 22 * n1 + n2, x = xg - off;
-                if (row < R && (unsigned)x < (unsigned)R) {
-                    const int p = row * R + x;
-                    const float am = a.amp[p];
-                    if (am != 0.f) {
-                        float ang = ph[p];
-                        if (tt) ang += tt[p];
-                        // centred mask: exp(-i pi (N+1)/N (x + y)) on the padded grid, angle reduced mod 2 pi in integers (k_pyr_rows)
-                        const float pang = a.phasor_mult ? pi_over_n * (float)((a.phasor_mult * (xg + row + off)) % (2 * N)) : 0.f;
-                        float s, co;
-                        sincosf(ang - pang, &s, &co);
-                        v[n1] = v2{am * co, am * s};
-                    }
-                }
-            }
+            if (n1 >= n1_lo && n1 <= n1_hi) v[n1] = ex[ca * SEQ + 22 * (n1 - n1_lo) + n2];
         }
+    }
+    __syncthreads();                                              // the field has been read: ex becomes the exchange buffer
+    if (tid < 176) {
         f528::dft24<false>(v);
 #pragma unroll
         for (int k1 = 1; k1 < 24; ++k1) v[k1] = f528::cmul_tw<false>(v[k1], tws[k1 * kTws + n2]);
 #pragma unroll
-        for (int k1 = 0; k1 < 24; ++k1) ex[c * SEQ + n2 * S2 + k1] = v[k1];
+        for (int k1 = 0; k1 < 24; ++k1) ex[ca * SEQ + n2 * S2 + k1] = v[k1];
     }
     __syncthreads();
     {
         const int c = tid / 24, k1 = tid - 24 * c, row = y0 + c;
         v2 u[22];
 #pragma unroll
-        for (int n2 = 0; n2 < 22; ++n2) u[n2] = ex[c * SEQ + n2 * S2 + k1];
+        for (int n2b = 0; n2b < 22; ++n2b) u[n2b] = ex[c * SEQ + n2b * S2 + k1];
         f528::dft22<false>(u);
         if (row < R) {
             v2* t1 = reinterpret_cast<v2*>(a.t1) + (((size_t)e * a.n_theta_chunk + th) * R + row) * N + k1;
@@ -89,50 +154,66 @@ __global__ void __launch_bounds__(kLanes528) k_pyr528_rows(const PyrArgs<float> 
     }
 }
 
-// ---- P2: grid = (72 = 66 column blocks padded to a multiple of 8, chunk, E) --------------------------------------------------------
-template <bool SHIFT>
-__global__ void __launch_bounds__(kLanes528) k_pyr528_cols(const PyrArgs<float> a) {
-    constexpr int N = f528::kN, SF = 200, SI = 184;               // ex[n2][k1][c] rows of 200, then ex[k1][m1][c] rows of 184 (both = 8 mod 16)
-    __shared__ v2 ex[24 * SI];                                    // 4416 >= 22 * 200
+// ---- P2: grid = (8 XCDs x 5 slots for 33 blocks of 16 columns, chunk, E); 384 lanes = 16 columns x 24 ---------------------------------------------------
+// 16 columns are one 128-byte line of T1 / T2 per row: a wave's load or store touches 4 whole lines.  (With 8 columns per workgroup
+// -- half lines, the other half read and written by a neighbouring workgroup -- the texture addresser was busy 60 % of the kernel
+// against 38 % here, and the L2 served every line of T1 twice.)
+// N1LO, N1CNT: the 24-point inputs n1 in [N1LO, N1LO + N1CNT) can lie inside the pupil rows (y = 22 n1 + n2 - off); the others are
+// zero padding for every lane.
+template <bool SHIFT, int N1LO, int N1CNT>
+__global__ void __launch_bounds__(384, 3) k_pyr528_cols(const PyrArgs<float> a) {
+    constexpr int N = f528::kN, CB = 16, SF = 24 * CB, SI = 22 * CB;   // ex[n2][k1][c], then ex[k1][m1][c]: 16 lanes = 16 c = 32 banks
+    __shared__ v2 ex[22 * SF];                                    // 8448 = 24 * SI
     __shared__ v2 tws[24 * kTws];
-    const int tid = threadIdx.x, c = tid & 7, j = tid >> 3, R = a.R, off = a.off;
-    load_tws(tws, a.tw, tid);
-    // blockIdx.x % 8 is the XCD: each XCD takes a contiguous range of column blocks (k_pyr_cols)
-    const int nblk = N / 8, per_xcd = gridDim.x / 8;
-    const int blk = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (blk >= nblk) return;                                      // padding of the grid (uniform for the workgroup)
-    const int e = blockIdx.z, th = blockIdx.y, kx0 = blk * 8;
-    const int jx0 = SHIFT ? (kx0 + N / 2) % N : kx0;              // 8 divides N / 2: the block's shifted columns stay contiguous
-    const int n1_lo = off / 22, n1_hi = (off + R - 1) / 22;
+    const int tid = threadIdx.x, c = tid & 15, j = tid >> 4, R = a.R, off = a.off;
+    AO_PSTAMP(0);
+    for (int i = tid; i < 24 * kTws; i += 384) {
+        const int k1 = i / kTws, n2 = i - kTws * k1;
+        tws[i] = reinterpret_cast<const v2*>(a.tw)[n2 < 22 ? k1 * n2 : 0];
+    }
+    // blockIdx.x % 8 is the XCD (workgroups go round-robin over the 8 XCDs): XCD x takes the blocks 4 x .. 4 x + 3 of every env and
+    // the 33rd block of the envs with e % 8 = x, so that an XCD's L2 keeps the 5 blocks of the mask it needs (0.3 MB) while T1 / T2
+    // stream through it.  (Blocks dealt round-robin: every L2 reads all 2.2 MB of the mask between 3 GB of streaming, and misses.)
+    const int e = blockIdx.z, th = blockIdx.y, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    int kx0;
+    if (a.generic_fft & 1024) {                                   // diagnostic: blocks dealt round-robin
+        if (blockIdx.x >= 33) return;
+        kx0 = blockIdx.x * CB;
+    } else {
+        if (slot == 4 && (e & 7) != xcd) return;                 // (uniform for the workgroup)
+        kx0 = (slot < 4 ? 4 * xcd + slot : 32) * CB;
+    }
+    // shifted column of frequency kx0 + c (N / 2 = 264 is 8 mod 16: with the shift a block is two half lines, and one block wraps)
+    const int jx = SHIFT ? (kx0 + c + N / 2) % N : kx0 + c;
+    const v2* t1 = reinterpret_cast<const v2*>(a.t1) + ((size_t)e * a.n_theta_chunk + th) * R * N;
+    v2* t2 = reinterpret_cast<v2*>(a.t2) + ((size_t)e * a.n_theta_chunk + th) * N * N;
+    const v2* mk = reinterpret_cast<const v2*>(a.mask);
+    // the mask values of this lane's frequencies: shifted position i holds frequency (i + N/2) mod N, so frequency k1 + 24 k2 sits at
+    // i = k1 + 24 ((k2 + 11) mod 22)   (N / 2 = 24 x 11; Pyramid.py:486-497)
+    const unsigned oj = (unsigned)(j * N + jx);
     v2 v[24];
     if (j < 22) {
-        const v2* t1 = reinterpret_cast<const v2*>(a.t1) + ((size_t)e * a.n_theta_chunk + th) * R * N + kx0 + c;
+        const unsigned o = (unsigned)((22 * N1LO + j - off) * N + kx0 + c);            // (wraps for a lane above the pupil: not used then)
 #pragma unroll
         for (int n1 = 0; n1 < 24; ++n1) {
-            v[n1] = v2{0.f, 0.f};
-            if (n1 >= n1_lo && n1 <= n1_hi) {
-                const int y = 22 * n1 + j - off;
-                if ((unsigned)y < (unsigned)R) v[n1] = t1[(size_t)y * N];
-            }
+            const int y = 22 * n1 + j - off;
+            v[n1] = (n1 >= N1LO && n1 < N1LO + N1CNT && (unsigned)y < (unsigned)R) ? t1[o + (unsigned)(22 * N * (n1 - N1LO))] : v2{0.f, 0.f};
         }
         f528::dft24<false>(v);
 #pragma unroll
         for (int k1 = 1; k1 < 24; ++k1) v[k1] = f528::cmul_tw<false>(v[k1], tws[k1 * kTws + j]);
 #pragma unroll
-        for (int k1 = 0; k1 < 24; ++k1) ex[j * SF + k1 * 8 + c] = v[k1];
+        for (int k1 = 0; k1 < 24; ++k1) ex[j * SF + k1 * CB + c] = v[k1];
     }
-    // the mask values of this lane's frequencies: shifted position i holds frequency (i + N/2) mod N, so frequency k1 + 24 k2 sits at
-    // i = k1 + 24 ((k2 + 11) mod 22)   (N / 2 = 24 x 11; Pyramid.py:486-497)
-    v2 m[22];
-    {
-        const v2* mk = reinterpret_cast<const v2*>(a.mask) + jx0 + c;
-#pragma unroll
-        for (int i2 = 0; i2 < 22; ++i2) m[i2] = mk[(size_t)(j + 24 * i2) * N];
-    }
+    AO_PSTAMP(1);
     __syncthreads();
+    AO_PSTAMP(2);
+    v2 m[22];                                                     // (requested before the first barrier they were 50 us slower: 44 registers)
+#pragma unroll
+    for (int i2 = 0; i2 < 22; ++i2) m[i2] = mk[oj + (unsigned)(24 * N * i2)];
     v2 u[22];
 #pragma unroll
-    for (int n2 = 0; n2 < 22; ++n2) u[n2] = ex[n2 * SF + j * 8 + c];
+    for (int n2 = 0; n2 < 22; ++n2) u[n2] = ex[n2 * SF + j * CB + c];
     f528::dft22<false>(u);
     v2 g[22];
 #pragma unroll
@@ -143,43 +224,52 @@ __global__ void __launch_bounds__(kLanes528) k_pyr528_cols(const PyrArgs<float> 
     f528::dft22<true>(g);
 #pragma unroll
     for (int m1 = 1; m1 < 22; ++m1) g[m1] = f528::cmul_tw<true>(g[m1], tws[j * kTws + m1]);
+    AO_PSTAMP(3);
     __syncthreads();                                              // every lane has its forward values
+    AO_PSTAMP(4);
 #pragma unroll
-    for (int m1 = 0; m1 < 22; ++m1) ex[j * SI + m1 * 8 + c] = g[m1];
+    for (int m1 = 0; m1 < 22; ++m1) ex[j * SI + m1 * CB + c] = g[m1];
     __syncthreads();
+    AO_PSTAMP(5);
     if (j < 22) {
 #pragma unroll
-        for (int k1 = 0; k1 < 24; ++k1) v[k1] = ex[k1 * SI + j * 8 + c];
+        for (int k1 = 0; k1 < 24; ++k1) v[k1] = ex[k1 * SI + j * CB + c];
         f528::dft24<true>(v);
-        v2* t2 = reinterpret_cast<v2*>(a.t2) + ((size_t)e * a.n_theta_chunk + th) * N * N + jx0 + c;
+        AO_PSTAMP(6);
 #pragma unroll
-        for (int m2 = 0; m2 < 24; ++m2) t2[(size_t)(j + 22 * m2) * N] = v[m2];
+        for (int m2 = 0; m2 < 24; ++m2) t2[oj + (unsigned)(22 * N * m2)] = v[m2];
     }
+    AO_PSTAMP(7);
 }
 
 // ---- P3: grid = (cam / G, E): G camera rows = G nb rows of T2 per modulation point, in batches of 8 sequences ------------------------
-__global__ void __launch_bounds__(kLanes528) k_pyr528_rows_inv(const PyrArgs<float> a, int accumulate, int G) {
-    constexpr int N = f528::kN, SEQ = 568, S1 = 23;               // ex[c][k1][m1]
+// The sums of |.|^2 over the rows of a camera row stay in registers: lane t owns the columns x = t, t + 192, t + 384 of all G camera rows.
+template <int G>
+__global__ void __launch_bounds__(kLanes528, 3) k_pyr528_rows_inv(const PyrArgs<float> a, int accumulate) {
+    constexpr int N = f528::kN, SEQ = 552, S1 = 23, NX = (N + kLanes528 - 1) / kLanes528;   // ex[c][k1][m1]
     __shared__ v2 ex[8 * SEQ];
     __shared__ v2 tws[24 * kTws];
-    __shared__ float acc[4 * N];                                  // [G][N] column sums of |.|^2 over the nb rows and the chunk
     float* pw = reinterpret_cast<float*>(ex);                     // [8][N] |.|^2 of the batch (after the exchange has been read)
     const int tid = threadIdx.x, nb = N / a.cam, chunk = a.n_theta_chunk;
     load_tws(tws, a.tw, tid);
-    for (int i = tid; i < G * N; i += kLanes528) acc[i] = 0.f;
     const int e = blockIdx.y, cr0 = blockIdx.x * G;
     const int per_g = chunk * nb, S = G * per_g;                  // sequence s = (g chunk + th) nb + q: row (cr0 + g) nb + q of point th
     const float scale = 1.f / ((float)N * (float)N * (float)N * (float)N);   // ifft2 normalisation 1/N^2 on the amplitude
     const int cb = tid / 24, k1 = tid - 24 * cb;
     const int ca = tid / 22, m1 = tid - 22 * ca;
+    float acc[G][NX];
+#pragma unroll
+    for (int gi = 0; gi < G; ++gi)
+#pragma unroll
+        for (int t = 0; t < NX; ++t) acc[gi][t] = 0.f;
+#pragma unroll 1
     for (int s0 = 0; s0 < S; s0 += 8) {
         v2 g[22];
         {
             const int s = s0 + cb;
             const bool valid = s < S;
             const int gi = s / per_g, rem = s - gi * per_g, th = rem / nb, q = rem - th * nb;
-            const v2* t2 = reinterpret_cast<const v2*>(a.t2) +
-                           (valid ? (((size_t)e * chunk + th) * N + (size_t)(cr0 + gi) * nb + q) * N + k1 : 0);
+            const v2* t2 = reinterpret_cast<const v2*>(a.t2) + (valid ? (((size_t)e * chunk + th) * N + (size_t)(cr0 + gi) * nb + q) * N + k1 : 0);
 #pragma unroll
             for (int k2 = 0; k2 < 22; ++k2) g[k2] = valid ? t2[24 * k2] : v2{0.f, 0.f};
         }
@@ -205,51 +295,82 @@ __global__ void __launch_bounds__(kLanes528) k_pyr528_rows_inv(const PyrArgs<flo
             for (int m2 = 0; m2 < 24; ++m2) pw[ca * N + m1 + 22 * m2] = p[m2];
         }
         __syncthreads();
+        // sequences s0 .. s0 + 7 belong to camera rows g_first .. (uniform); slot cc goes to acc[g(cc)]
         const int n_in = min(8, S - s0);
-        for (int x = tid; x < N; x += kLanes528) {
-            int g_prev = s0 / per_g;
-            float run = 0.f;
-            for (int cc = 0; cc < n_in; ++cc) {
-                const int gi = (s0 + cc) / per_g;
-                if (gi != g_prev) {
-                    acc[g_prev * N + x] += run;
-                    run = 0.f;
-                    g_prev = gi;
+#pragma unroll
+        for (int t = 0; t < NX; ++t) {
+            const int x = tid + t * kLanes528;
+            if (x < N) {
+#pragma unroll
+                for (int gi = 0; gi < G; ++gi) {
+                    const int lo = max(gi * per_g - s0, 0), hi = min((gi + 1) * per_g - s0, n_in);   // slots of camera row gi in this batch
+                    float run = 0.f;
+                    for (int cc = lo; cc < hi; ++cc) run += pw[cc * N + x];
+                    acc[gi][t] += run;
                 }
-                run += pw[cc * N + x];
             }
-            acc[g_prev * N + x] += run;
         }
+    }
+    __syncthreads();                                              // the last batch's pw has been read
+#pragma unroll
+    for (int t = 0; t < NX; ++t) {
+        const int x = tid + t * kLanes528;
+        if (x < N)
+#pragma unroll
+            for (int gi = 0; gi < G; ++gi) pw[gi * N + x] = acc[gi][t];
     }
     __syncthreads();
     float* fr = a.frame + (size_t)e * a.cam * a.cam + (size_t)cr0 * a.cam;
     for (int i = tid; i < G * a.cam; i += kLanes528) {
         const int gi = i / a.cam, cc = i - gi * a.cam;
         float s = 0.f;
-        for (int q = 0; q < nb; ++q) s += acc[gi * N + cc * nb + q];
+        for (int q = 0; q < nb; ++q) s += pw[gi * N + cc * nb + q];
         fr[i] = accumulate ? fr[i] + s : s;
     }
 }
 
+#ifdef AO_PYR_STAMPS
+}  // namespace ao
+extern "C" int aoenv_debug_pyr_occupancy(int* out3) {            // resident workgroups per CU of the three passes (runtime's answer)
+    using namespace ao;
+    int r = 0;
+    r |= hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[0], k_pyr528_rows, kLanes528, 0) != hipSuccess;
+    r |= hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[1], k_pyr528_cols<false, 6, 12>, 384, 0) != hipSuccess;
+    r |= hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[2], k_pyr528_rows_inv<4>, kLanes528, 0) != hipSuccess;
+    return r;
+}
+namespace ao {
+#endif
+
 // 0: this geometry is not covered (the caller runs the Stockham passes of pyr_kernels.hip)
 int pyramid528_supported(const PyrArgs<float>& a) {
-    return a.N == f528::kN && a.R <= a.N && a.off >= 0 && a.off + a.R <= a.N && a.cam > 0 && a.N % a.cam == 0 && !a.generic_fft;
+    return a.N == f528::kN && a.R <= a.N && a.off >= 0 && a.off + a.R <= a.N && a.cam > 0 && a.N % a.cam == 0 && !(a.generic_fft & 512);
 }
 
 int launch_pyramid528(const PyrArgs<float>& base, int n_theta, int chunk, hipStream_t st) {
     PyrArgs<float> a = base;
-    const int N = a.N, R = a.R;
+    const int R = a.R;
     const int G = a.cam % 4 == 0 ? 4 : (a.cam % 2 == 0 ? 2 : 1);
+    const bool c3 = a.off / 22 == 6 && (a.off + R - 1) / 22 == 17;           // R = 240 centred in 528: inputs n1 = 6 .. 17
     for (int t0 = 0; t0 < n_theta; t0 += chunk) {
         a.theta0 = t0;
         a.n_theta_chunk = (n_theta - t0) < chunk ? (n_theta - t0) : chunk;
+        a.seq_per_block = 22 * ((a.off + R - 1) / 22 - a.off / 22 + 1);       // field columns per row that P1 evaluates
+        a.magic_seq = fft_magic((unsigned)a.seq_per_block);
         hipLaunchKernelGGL(k_pyr528_rows, dim3(cdiv(R, 8), a.n_theta_chunk, a.n_env), dim3(kLanes528), 0, st, a);
-        const dim3 g2(cdiv(N / 8, 8) * 8, a.n_theta_chunk, a.n_env);
-        if (a.centering)
-            hipLaunchKernelGGL(k_pyr528_cols<false>, g2, dim3(kLanes528), 0, st, a);
-        else
-            hipLaunchKernelGGL(k_pyr528_cols<true>, g2, dim3(kLanes528), 0, st, a);
-        hipLaunchKernelGGL(k_pyr528_rows_inv, dim3(a.cam / G, a.n_env), dim3(kLanes528), 0, st, a, t0 > 0 ? 1 : 0, G);
+        const dim3 g2(8 * 5, a.n_theta_chunk, a.n_env);               // 33 blocks of 16 columns: 4 per XCD + 1 (see the kernel)
+        if (a.centering) {
+            if (c3) hipLaunchKernelGGL((k_pyr528_cols<false, 6, 12>), g2, dim3(384), 0, st, a);
+            else hipLaunchKernelGGL((k_pyr528_cols<false, 0, 24>), g2, dim3(384), 0, st, a);
+        } else {
+            if (c3) hipLaunchKernelGGL((k_pyr528_cols<true, 6, 12>), g2, dim3(384), 0, st, a);
+            else hipLaunchKernelGGL((k_pyr528_cols<true, 0, 24>), g2, dim3(384), 0, st, a);
+        }
+        const dim3 g3(a.cam / G, a.n_env);
+        const int accumulate = t0 > 0 ? 1 : 0;
+        if (G == 4) hipLaunchKernelGGL(k_pyr528_rows_inv<4>, g3, dim3(kLanes528), 0, st, a, accumulate);
+        else if (G == 2) hipLaunchKernelGGL(k_pyr528_rows_inv<2>, g3, dim3(kLanes528), 0, st, a, accumulate);
+        else hipLaunchKernelGGL(k_pyr528_rows_inv<1>, g3, dim3(kLanes528), 0, st, a, accumulate);
         AO_HIP(hipGetLastError());
     }
     return 0;

@@ -293,33 +293,42 @@ def test_c2_geometry_1000_envs_ragged_shard():
     assert float(big[-1][3].std()) > 0
 
 
-@pytest.mark.parametrize("modulation", [0.0, 3.0])
-def test_c3_pyramid_528_register_passes_match_the_stockham_passes(modulation):
+@pytest.mark.parametrize("n_sub,ppx,centering,modulation", [(40, 6, True, 0.0), (40, 6, True, 3.0), (7, 24, False, 2.0), (18, 12, True, 0.0),
+                                                            (29, 8, False, 0.0)])
+def test_c3_pyramid_528_register_passes_match_the_stockham_passes(n_sub, ppx, centering, modulation):
     """nRes = 528 in float32 runs the 24 x 22 register-resident transform (pyr528_kernels.hip); diagnostic option 99 bit 512
-    puts the same shard back on the Stockham passes of pyr_kernels.hip (what float64 and every other length run).  Same field,
-    same mask, different order of the float32 butterflies: frames agree to float32 rounding of the brightest pixel."""
+    puts the same shard back on the Stockham passes of pyr_kernels.hip (what float64 and every other length run, pinned to the
+    reference by the golden replays).  Same field, same mask, different order of the float32 butterflies: frames agree to float32
+    rounding of the brightest pixel.  Geometries: BASELINE configs[2] (R = 240: the specialised column pass, 4 camera rows per
+    workgroup), and other ways to nRes = 528 -- 7 x 24 px (R = 168, 22-pixel camera: 2 camera rows per workgroup), 18 x 12 px (R = 216)
+    and 29 x 8 px (R = 232) -- with the mask centred on a pixel corner or on a pixel (fftshift between the transforms)."""
     import torch
     from rlao_amd import _lib as L
     from rlao_amd.env import BatchedAOEnv
+    geo = dict(C3, diameter=8.0 * n_sub / 40, nSubaperture=n_sub, nPixelPerSubap=ppx, nModes=min(50, n_sub * n_sub // 2),
+               modulation=modulation, psfCentering=centering)
     env = BatchedAOEnv(n_envs=4, device=0, dtype="f32", env_seed_stride=1)
     try:
-        env.set_params(dict(C3, modulation=modulation), camera="ideal", wfs_type="pyramid")
+        env.set_params(geo, camera="ideal", wfs_type="pyramid")
+        assert env._pyr_tables.nRes == 528 and env.R == n_sub * ppx
         env.generate_new_phase_screen(5)
         env.dm.coefs = 0
         frames, signals = [], []
-        for generic in (0, 512, 0):
+        for generic in (0, 512, 0, 1024):
             L.check(env._shard.lib.aoenv_set_option(env._shard.h, 99, generic))
             env.measure()
             frames.append(env._shard.download(L.B_FRAME, (4, env.cam_res, env.cam_res)).astype(np.float64))
             signals.append(env._shard.download(L.B_SIGNAL, (4, env.nSignal)).astype(np.float64))
         torch.cuda.synchronize()
         assert np.array_equal(frames[0], frames[2]) and np.array_equal(signals[0], signals[2])      # bitwise reruns
+        assert np.array_equal(frames[0], frames[3])                                                # column blocks dealt differently: same bits
         assert not np.array_equal(frames[0], frames[1])                                            # the option did switch paths
         peak = frames[1].max()
         assert peak > 0 and np.isfinite(frames[0]).all()
         err = np.abs(frames[0] - frames[1]).max() / peak
         serr = np.abs(signals[0] - signals[1]).max() / np.abs(signals[1]).max()
-        print(f"528 passes vs Stockham, modulation {modulation}: frame {err:.2e} of the peak, signal {serr:.2e} of the max")
+        print(f"528 passes vs Stockham, {n_sub} x {ppx} px, centering {centering}, modulation {modulation}: frame {err:.2e} of the peak, "
+              f"signal {serr:.2e} of the max")
         assert err < 2e-6 and serr < 2e-5, (err, serr)
     finally:
         env.close()
