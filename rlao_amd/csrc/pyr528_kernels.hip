@@ -27,13 +27,23 @@ using f528::v2;
 // diagnostic build (-DAO_PYR_STAMPS, scripts/diag_pyr_stamps.py): s_memtime per wave at the phases of the column pass
 #ifdef AO_PYR_STAMPS
 __device__ unsigned long long g_pstamps[32 * 40 * 6 * 8];
+__device__ unsigned long long g_prt[32 * 40 * 3];               // s_memrealtime (100 MHz) at the start and the end of wave 0
 #define AO_PSTAMP(i) do { if ((threadIdx.x & 63) == 0 && blockIdx.y == 0 && blockIdx.z >= 500 && blockIdx.z < 532) \
     g_pstamps[(((blockIdx.z - 500) * 40 + blockIdx.x) * 6 + (threadIdx.x >> 6)) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define AO_PRT(i) do { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z >= 500 && blockIdx.z < 532) \
+    g_prt[((blockIdx.z - 500) * 40 + blockIdx.x) * 3 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define AO_PHW() do { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z >= 500 && blockIdx.z < 532) \
+    g_prt[((blockIdx.z - 500) * 40 + blockIdx.x) * 3 + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492); } while (0)
 extern "C" int aoenv_debug_pstamps(unsigned long long* h_out) {
     return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_pstamps), sizeof(unsigned long long) * 32 * 40 * 6 * 8) == hipSuccess ? 0 : 1;
 }
+extern "C" int aoenv_debug_prt(unsigned long long* h_out) {
+    return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_prt), sizeof(unsigned long long) * 32 * 40 * 3) == hipSuccess ? 0 : 1;
+}
 #else
 #define AO_PSTAMP(i) do { } while (0)
+#define AO_PRT(i) do { } while (0)
+#define AO_PHW() do { } while (0)
 #endif
 #ifdef AO_PYR_STAMPS
 }  // namespace ao
@@ -42,13 +52,37 @@ namespace ao {
 #endif
 constexpr int kLanes528 = 192, kTws = 23;                         // twiddle table [k1][n2] with rows of 23 (odd: see P2's inverse reads)
 
-// w_528^(k1 n2), k1 < 24, n2 < 22, from the N-entry table of the env (k1 n2 <= 483 < 528)
-__device__ inline void load_tws(v2* __restrict__ tws, const float* __restrict__ tw, int tid) {
-    const v2* t = reinterpret_cast<const v2*>(tw);
-    for (int i = tid; i < 24 * kTws; i += kLanes528) {
-        const int k1 = i / kTws, n2 = i - kTws * k1;
-        tws[i] = t[n2 < 22 ? k1 * n2 : 0];
+// LDS bytes of the three passes, passed at launch.  The buffers are DYNAMIC shared memory on purpose: with a static size the compiler
+// works out the LDS-limited occupancy (3 waves per SIMD if the workgroups spread evenly over the 4 SIMDs) and pads the kernel's
+// register allocation up to what that occupancy allows (.amdhsa_next_free_vgpr 129 for 90-118 registers in use).  A workgroup of 3
+// or 6 waves does not spread evenly -- the column pass puts 2, 2, 1, 1 waves on the SIMDs -- so a second workgroup needs a fourth
+// slot on two of them, and with 136 registers per lane allocated a SIMD holds three: one workgroup per CU instead of two (seen in
+// the per-CU intervals of scripts/diag_pyr_stamps.py; scripts/ubench/lds_occupancy.hip shows the LDS itself admits floor(160 / KB)).
+constexpr size_t kLdsRows = (8 * 550 + 24 * kTws) * sizeof(v2), kLdsCols = (22 * 24 * 16 + 24 * kTws) * sizeof(v2),
+                 kLdsRowsInv = (8 * 552 + 24 * kTws) * sizeof(v2);
+
+
+// w_528^(k1 n2), k1 < 24, n2 < 22, from the N-entry table of the env (k1 n2 <= 483 < 528), in two steps: the loads are issued at the
+// top of a kernel, ahead of the pass's own first loads, and the values are written to LDS once those have been issued too -- one
+// memory latency per workgroup instead of two in a row (a workgroup lives for ~9 us, a load takes 1-2).
+template <int LANES>
+struct TwsRegs {
+    static constexpr int K = (24 * kTws + LANES - 1) / LANES;
+    v2 r[K];
+};
+template <int LANES>
+__device__ inline void tws_issue(TwsRegs<LANES>& t, const float* __restrict__ tw, int tid) {
+#pragma unroll
+    for (int u = 0; u < TwsRegs<LANES>::K; ++u) {
+        const int i = tid + u * LANES, k1 = i / kTws, n2 = i - kTws * k1;
+        t.r[u] = reinterpret_cast<const v2*>(tw)[(i < 24 * kTws && n2 < 22) ? k1 * n2 : 0];
     }
+}
+template <int LANES>
+__device__ inline void tws_commit(const TwsRegs<LANES>& t, v2* __restrict__ tws, int tid) {
+#pragma unroll
+    for (int u = 0; u < TwsRegs<LANES>::K; ++u)
+        if (tid + u * LANES < 24 * kTws) tws[tid + u * LANES] = t.r[u];
 }
 
 // sin and cos of a float32 angle: three-term Cody-Waite reduction by pi/2 with fused multiply-adds (exact to float32 rounding
@@ -77,10 +111,12 @@ __device__ inline void sincos_cw(float x, float* sn, float* cs) {
 // ---- P1: grid = (ceil(R / 8), chunk, E) -----------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kLanes528) k_pyr528_rows(const PyrArgs<float> a) {
     constexpr int N = f528::kN, SEQ = 550, S2 = 25;               // ex[c][n2][k1]: rows of 25 (odd) -> conflict-free writes
-    __shared__ v2 ex[8 * SEQ];                                    // first the field of the 8 rows: fld[c][x - 22 n1_lo]
-    __shared__ v2 tws[24 * kTws];
+    extern __shared__ __align__(16) unsigned char lds_raw[];      // dynamic on purpose: see kLdsRows
+    v2* ex = reinterpret_cast<v2*>(lds_raw);                      // [8 * SEQ]  first the field of the 8 rows: fld[c][x - 22 n1_lo]
+    v2* tws = ex + 8 * SEQ;                                       // [24 * kTws]
     const int tid = threadIdx.x, R = a.R, off = a.off;
-    load_tws(tws, a.tw, tid);
+    TwsRegs<kLanes528> twr;
+    tws_issue(twr, a.tw, tid);
     const int e = blockIdx.z, th = blockIdx.y, y0 = blockIdx.x * 8;
     const int n1_lo = off / 22, n1_hi = (off + R - 1) / 22;       // the 24-point inputs that can be inside the pupil, for any lane
     {
@@ -121,6 +157,7 @@ __global__ void __launch_bounds__(kLanes528) k_pyr528_rows(const PyrArgs<float> 
             }
         }
     }
+    tws_commit(twr, tws, tid);
     __syncthreads();
     const int ca = tid / 22, n2 = tid - 22 * ca;
     v2 v[24];
@@ -161,16 +198,17 @@ __global__ void __launch_bounds__(kLanes528) k_pyr528_rows(const PyrArgs<float> 
 // N1LO, N1CNT: the 24-point inputs n1 in [N1LO, N1LO + N1CNT) can lie inside the pupil rows (y = 22 n1 + n2 - off); the others are
 // zero padding for every lane.
 template <bool SHIFT, int N1LO, int N1CNT>
-__global__ void __launch_bounds__(384, 3) k_pyr528_cols(const PyrArgs<float> a) {
+__global__ void __launch_bounds__(384, 4) k_pyr528_cols(const PyrArgs<float> a) {
     constexpr int N = f528::kN, CB = 16, SF = 24 * CB, SI = 22 * CB;   // ex[n2][k1][c], then ex[k1][m1][c]: 16 lanes = 16 c = 32 banks
-    __shared__ v2 ex[22 * SF];                                    // 8448 = 24 * SI
-    __shared__ v2 tws[24 * kTws];
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    v2* ex = reinterpret_cast<v2*>(lds_raw);                      // [22 * SF = 24 * SI = 8448]
+    v2* tws = ex + 22 * SF;                                       // [24 * kTws]
     const int tid = threadIdx.x, c = tid & 15, j = tid >> 4, R = a.R, off = a.off;
     AO_PSTAMP(0);
-    for (int i = tid; i < 24 * kTws; i += 384) {
-        const int k1 = i / kTws, n2 = i - kTws * k1;
-        tws[i] = reinterpret_cast<const v2*>(a.tw)[n2 < 22 ? k1 * n2 : 0];
-    }
+    AO_PRT(0);
+    AO_PHW();
+    TwsRegs<384> twr;
+    tws_issue(twr, a.tw, tid);
     // blockIdx.x % 8 is the XCD (workgroups go round-robin over the 8 XCDs): XCD x takes the blocks 4 x .. 4 x + 3 of every env and
     // the 33rd block of the envs with e % 8 = x, so that an XCD's L2 keeps the 5 blocks of the mask it needs (0.3 MB) while T1 / T2
     // stream through it.  (Blocks dealt round-robin: every L2 reads all 2.2 MB of the mask between 3 GB of streaming, and misses.)
@@ -192,13 +230,23 @@ __global__ void __launch_bounds__(384, 3) k_pyr528_cols(const PyrArgs<float> a) 
     // i = k1 + 24 ((k2 + 11) mod 22)   (N / 2 = 24 x 11; Pyramid.py:486-497)
     const unsigned oj = (unsigned)(j * N + jx);
     v2 v[24];
-    if (j < 22) {
-        const unsigned o = (unsigned)((22 * N1LO + j - off) * N + kx0 + c);            // (wraps for a lane above the pupil: not used then)
+    {
+        // every lane loads (rows clamped into the pupil, lanes j >= 22 the rows of j = 21): no branches around the loads, so that the
+        // twiddle values requested before them can be waited for alone
+        const int jj = j < 22 ? j : 21;
 #pragma unroll
         for (int n1 = 0; n1 < 24; ++n1) {
-            const int y = 22 * n1 + j - off;
-            v[n1] = (n1 >= N1LO && n1 < N1LO + N1CNT && (unsigned)y < (unsigned)R) ? t1[o + (unsigned)(22 * N * (n1 - N1LO))] : v2{0.f, 0.f};
+            v[n1] = v2{0.f, 0.f};
+            if (n1 >= N1LO && n1 < N1LO + N1CNT) {
+                const int y = 22 * n1 + jj - off, yc = min(max(y, 0), R - 1);
+                const v2 t = t1[(unsigned)(yc * N + kx0 + c)];
+                v[n1] = y == yc ? t : v2{0.f, 0.f};
+            }
         }
+    }
+    tws_commit(twr, tws, tid);
+    __syncthreads();
+    if (j < 22) {
         f528::dft24<false>(v);
 #pragma unroll
         for (int k1 = 1; k1 < 24; ++k1) v[k1] = f528::cmul_tw<false>(v[k1], tws[k1 * kTws + j]);
@@ -240,18 +288,21 @@ __global__ void __launch_bounds__(384, 3) k_pyr528_cols(const PyrArgs<float> a) 
         for (int m2 = 0; m2 < 24; ++m2) t2[oj + (unsigned)(22 * N * m2)] = v[m2];
     }
     AO_PSTAMP(7);
+    AO_PRT(1);
 }
 
 // ---- P3: grid = (cam / G, E): G camera rows = G nb rows of T2 per modulation point, in batches of 8 sequences ------------------------
 // The sums of |.|^2 over the rows of a camera row stay in registers: lane t owns the columns x = t, t + 192, t + 384 of all G camera rows.
 template <int G>
-__global__ void __launch_bounds__(kLanes528, 3) k_pyr528_rows_inv(const PyrArgs<float> a, int accumulate) {
+__global__ void __launch_bounds__(kLanes528, 4) k_pyr528_rows_inv(const PyrArgs<float> a, int accumulate) {
     constexpr int N = f528::kN, SEQ = 552, S1 = 23, NX = (N + kLanes528 - 1) / kLanes528;   // ex[c][k1][m1]
-    __shared__ v2 ex[8 * SEQ];
-    __shared__ v2 tws[24 * kTws];
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    v2* ex = reinterpret_cast<v2*>(lds_raw);                      // [8 * SEQ]
+    v2* tws = ex + 8 * SEQ;                                       // [24 * kTws]
     float* pw = reinterpret_cast<float*>(ex);                     // [8][N] |.|^2 of the batch (after the exchange has been read)
     const int tid = threadIdx.x, nb = N / a.cam, chunk = a.n_theta_chunk;
-    load_tws(tws, a.tw, tid);
+    TwsRegs<kLanes528> twr;
+    tws_issue(twr, a.tw, tid);
     const int e = blockIdx.y, cr0 = blockIdx.x * G;
     const int per_g = chunk * nb, S = G * per_g;                  // sequence s = (g chunk + th) nb + q: row (cr0 + g) nb + q of point th
     const float scale = 1.f / ((float)N * (float)N * (float)N * (float)N);   // ifft2 normalisation 1/N^2 on the amplitude
@@ -266,12 +317,19 @@ __global__ void __launch_bounds__(kLanes528, 3) k_pyr528_rows_inv(const PyrArgs<
     for (int s0 = 0; s0 < S; s0 += 8) {
         v2 g[22];
         {
-            const int s = s0 + cb;
-            const bool valid = s < S;
+            const bool valid = s0 + cb < S;
+            const int s = valid ? s0 + cb : S - 1;                // (a slot beyond the last sequence loads that one and zeroes it: no branch)
             const int gi = s / per_g, rem = s - gi * per_g, th = rem / nb, q = rem - th * nb;
-            const v2* t2 = reinterpret_cast<const v2*>(a.t2) + (valid ? (((size_t)e * chunk + th) * N + (size_t)(cr0 + gi) * nb + q) * N + k1 : 0);
+            const v2* t2 = reinterpret_cast<const v2*>(a.t2) + (((size_t)e * chunk + th) * N + (size_t)(cr0 + gi) * nb + q) * N + k1;
 #pragma unroll
-            for (int k2 = 0; k2 < 22; ++k2) g[k2] = valid ? t2[24 * k2] : v2{0.f, 0.f};
+            for (int k2 = 0; k2 < 22; ++k2) {
+                const v2 t = t2[24 * k2];
+                g[k2] = valid ? t : v2{0.f, 0.f};
+            }
+        }
+        if (s0 == 0) {                                            // (uniform) the twiddle table, requested before the first rows
+            tws_commit(twr, tws, tid);
+            __syncthreads();
         }
         f528::dft22<true>(g);
 #pragma unroll
@@ -334,9 +392,9 @@ __global__ void __launch_bounds__(kLanes528, 3) k_pyr528_rows_inv(const PyrArgs<
 extern "C" int aoenv_debug_pyr_occupancy(int* out3) {            // resident workgroups per CU of the three passes (runtime's answer)
     using namespace ao;
     int r = 0;
-    r |= hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[0], k_pyr528_rows, kLanes528, 0) != hipSuccess;
-    r |= hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[1], k_pyr528_cols<false, 6, 12>, 384, 0) != hipSuccess;
-    r |= hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[2], k_pyr528_rows_inv<4>, kLanes528, 0) != hipSuccess;
+    r |= hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[0], k_pyr528_rows, kLanes528, kLdsRows) != hipSuccess;
+    r |= hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[1], k_pyr528_cols<false, 6, 12>, 384, kLdsCols) != hipSuccess;
+    r |= hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[2], k_pyr528_rows_inv<4>, kLanes528, kLdsRowsInv) != hipSuccess;
     return r;
 }
 namespace ao {
@@ -345,6 +403,13 @@ namespace ao {
 // 0: this geometry is not covered (the caller runs the Stockham passes of pyr_kernels.hip)
 int pyramid528_supported(const PyrArgs<float>& a) {
     return a.N == f528::kN && a.R <= a.N && a.off >= 0 && a.off + a.R <= a.N && a.cam > 0 && a.N % a.cam == 0 && !(a.generic_fft & 512);
+}
+
+// (the column pass needs more than the 64 KiB a kernel may use without asking)
+static int launch_cols(void (*kern)(const PyrArgs<float>), dim3 grid, hipStream_t st, const PyrArgs<float>& a) {
+    AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsCols));
+    hipLaunchKernelGGL(kern, grid, dim3(384), kLdsCols, st, a);
+    return 0;
 }
 
 int launch_pyramid528(const PyrArgs<float>& base, int n_theta, int chunk, hipStream_t st) {
@@ -357,20 +422,20 @@ int launch_pyramid528(const PyrArgs<float>& base, int n_theta, int chunk, hipStr
         a.n_theta_chunk = (n_theta - t0) < chunk ? (n_theta - t0) : chunk;
         a.seq_per_block = 22 * ((a.off + R - 1) / 22 - a.off / 22 + 1);       // field columns per row that P1 evaluates
         a.magic_seq = fft_magic((unsigned)a.seq_per_block);
-        hipLaunchKernelGGL(k_pyr528_rows, dim3(cdiv(R, 8), a.n_theta_chunk, a.n_env), dim3(kLanes528), 0, st, a);
+        hipLaunchKernelGGL(k_pyr528_rows, dim3(cdiv(R, 8), a.n_theta_chunk, a.n_env), dim3(kLanes528), kLdsRows, st, a);
         const dim3 g2(8 * 5, a.n_theta_chunk, a.n_env);               // 33 blocks of 16 columns: 4 per XCD + 1 (see the kernel)
         if (a.centering) {
-            if (c3) hipLaunchKernelGGL((k_pyr528_cols<false, 6, 12>), g2, dim3(384), 0, st, a);
-            else hipLaunchKernelGGL((k_pyr528_cols<false, 0, 24>), g2, dim3(384), 0, st, a);
+            if (c3) AO_TRY(launch_cols(k_pyr528_cols<false, 6, 12>, g2, st, a));
+            else AO_TRY(launch_cols(k_pyr528_cols<false, 0, 24>, g2, st, a));
         } else {
-            if (c3) hipLaunchKernelGGL((k_pyr528_cols<true, 6, 12>), g2, dim3(384), 0, st, a);
-            else hipLaunchKernelGGL((k_pyr528_cols<true, 0, 24>), g2, dim3(384), 0, st, a);
+            if (c3) AO_TRY(launch_cols(k_pyr528_cols<true, 6, 12>, g2, st, a));
+            else AO_TRY(launch_cols(k_pyr528_cols<true, 0, 24>, g2, st, a));
         }
         const dim3 g3(a.cam / G, a.n_env);
         const int accumulate = t0 > 0 ? 1 : 0;
-        if (G == 4) hipLaunchKernelGGL(k_pyr528_rows_inv<4>, g3, dim3(kLanes528), 0, st, a, accumulate);
-        else if (G == 2) hipLaunchKernelGGL(k_pyr528_rows_inv<2>, g3, dim3(kLanes528), 0, st, a, accumulate);
-        else hipLaunchKernelGGL(k_pyr528_rows_inv<1>, g3, dim3(kLanes528), 0, st, a, accumulate);
+        if (G == 4) hipLaunchKernelGGL(k_pyr528_rows_inv<4>, g3, dim3(kLanes528), kLdsRowsInv, st, a, accumulate);
+        else if (G == 2) hipLaunchKernelGGL(k_pyr528_rows_inv<2>, g3, dim3(kLanes528), kLdsRowsInv, st, a, accumulate);
+        else hipLaunchKernelGGL(k_pyr528_rows_inv<1>, g3, dim3(kLanes528), kLdsRowsInv, st, a, accumulate);
         AO_HIP(hipGetLastError());
     }
     return 0;

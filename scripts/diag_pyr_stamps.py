@@ -29,8 +29,30 @@ for i, l in enumerate(lab):
 occ = (C.c_int * 3)()
 if hasattr(lib, "aoenv_debug_pyr_occupancy") and lib.aoenv_debug_pyr_occupancy(occ) == 0:
     print("resident workgroups per CU (hipOccupancyMaxActiveBlocksPerMultiprocessor): rows", occ[0], "cols", occ[1], "rows_inv", occ[2])
-span = w[:, :, 7].max() - w[:, :, 0].min()
-print(f"sampled workgroups span {span} ticks: {span / ok.sum():.1f} ticks per workgroup chip-wide = {256 * span / ok.sum():.0f} per CU")
+rt = np.zeros((32, 40, 3), dtype=np.uint64)
+if hasattr(lib, "aoenv_debug_prt") and lib.aoenv_debug_prt(rt.ctypes.data_as(C.c_void_p)) == 0:
+    rt = rt.astype(np.int64)[ok]
+    d_rt = (rt[:, 1] - rt[:, 0]) / 100.0                          # us (100 MHz)
+    d_tk = w[:, 0, 7] - w[:, 0, 0]
+    print(f"wave 0 life: {np.median(d_rt):.2f} us = {np.median(d_tk):.0f} ticks -> {np.median(d_tk) / np.median(d_rt) / 1e3:.3f} ticks / ns")
+    hw = rt[:, 2]
+    xcc, hwid = (hw >> 32) & 0xF, hw & 0xFFFFFFFF
+    cu, sh, se = (hwid >> 8) & 0xF, (hwid >> 12) & 1, (hwid >> 13) & 7
+    key = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+    print("distinct CUs seen:", len(np.unique(key)), " XCCs:", np.unique(xcc), " SEs:", np.unique(se), " CU ids:", np.unique(cu))
+    over = []
+    for k in np.unique(key):
+        iv = rt[key == k]
+        ev = sorted([(a, 1) for a in iv[:, 0]] + [(b, -1) for b in iv[:, 1]])
+        cur = best = 0
+        for _, d in ev:
+            cur += d
+            best = max(best, cur)
+        over.append(best)
+    print("max workgroups at a time on one CU: histogram", np.bincount(over))
+    span = (rt[:, 1].max() - rt[:, 0].min()) / 100.0
+    print(f"the {ok.sum()} sampled workgroups ran within {span:.1f} us: {ok.sum() * np.median(d_rt) / span:.1f} of them at a time, "
+          f"{ok.sum() * np.median(d_rt) / span / 256:.2f} per CU if spread over the chip")
 life = w[:, :, 7].max(axis=1) - w[:, :, 0].min(axis=1)
 print("workgroup life (ticks): median", np.median(life), "min", life.min(), "max", life.max())
 # how many workgroups overlap in time on the sampled range (a rough view of the CU's occupancy)
