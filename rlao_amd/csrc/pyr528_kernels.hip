@@ -16,7 +16,7 @@
 //                 the rows of a camera row and the modulation points in LDS, binned to the camera row.
 // LDS layouts are chosen per pass so that the exchange is conflict-free for the lane order that keeps global accesses
 // contiguous (bank rules of ds_write_b64 / ds_read_b64, MI355X_MICROARCH.md; scripts/lds_banks_528.py counts them).
-// Measured at 1024 envs (C3): 410 + 1100 + 520 us against 837 + 2827 + 1583 us for the Stockham passes.
+// Measured at 1024 envs (C3, profiles/r03_C3_kernel_stats.csv): 395 + 975 + 535 us against 837 + 2827 + 1583 us for the Stockham passes.
 #include "common.hpp"
 #include "fft.hpp"
 #include "fft528.hpp"

@@ -23,7 +23,9 @@ SHORT = {"k_env_step_sh6": "env_step", "k_ring_prepare": "ring_prepare", "k_gemm
          "k_sh_spots_p6": "sh_spots", "k_sh_centroid": "sh_centroid", "k_sh_tail": "sh_tail", "k_recon_finish": "recon_finish",
          "k_pyr_rows": "pyr_rows", "k_pyr_cols": "pyr_cols", "k_pyr_rows_inv": "pyr_rows_inv", "k_pyr_slopes": "pyr_slopes",
          "k_detector": "detector", "k_detector_sh6": "detector_sh6", "k_dm_rows": "dm_rows", "k_scatter_minmax": "ring_scatter",
-         "k_ring_gemm_draw_ahead": "ring_gemm_draw_ahead", "k_ring_prepare_env": "ring_prepare_env"}
+         "k_ring_gemm_draw_ahead": "ring_gemm_draw_ahead", "k_ring_prepare_env": "ring_prepare_env",
+         # the nRes = 528 float32 passes (pyr528_kernels.hip) are the same stages as the Stockham passes; their keys carry "/528"
+         "k_pyr528_rows": "pyr_rows", "k_pyr528_cols": "pyr_cols", "k_pyr528_rows_inv": "pyr_rows_inv"}
 HBM_PEAK = 8.0e12
 
 
@@ -41,7 +43,7 @@ def split_name(name):
             break
     n = n[:cut]
     base, targs = (n.split("<", 1)[0], "<" + n.split("<", 1)[1]) if "<" in n else (n, "")
-    return SHORT.get(base, base), targs
+    return SHORT.get(base, base), targs + ("/528" if "528" in base else "")
 
 
 def key_of(name, grid):
