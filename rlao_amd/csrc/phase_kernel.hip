@@ -443,10 +443,16 @@ __global__ void __launch_bounds__(256) k_phase_mfma(const KArgs<float> a) {
 // instead of 10 dword loads, its taps are read as float4 from LDS, the pupil flags of 4 pixels are one load, the phase (and OPD)
 // rows are written as float4 -- the vector-memory path takes ~16 cycles per wave-instruction whatever its width.  Same arithmetic
 // per pixel (the same taps in the same order, the same k order of the product): results are bit-identical to k_phase_mfma.
-__global__ void __launch_bounds__(256) k_phase_mfma4(const KArgs<float> a) {
+// BAND (one layer): the layer tile of the WHOLE band -- 19 rows x (R + 4) columns, 37 KB at R = 480 -- is staged once, all its loads
+// in flight together, instead of a 19 x 132 tile per 128-column chunk: one memory latency and one pair of barriers per workgroup
+// instead of four (ELT size: a wave lived 43 us, 56 % of it waiting).
+// NQ: 16-byte loads per lane of a DM operand (Gy C rows, gx columns): ga_stride / 4 rounded up to even, <= 8 (n_act <= 128)
+template <bool BAND, int NQ>
+__global__ void __launch_bounds__(256, 4) k_phase_mfma4(const KArgs<float> a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int R = a.R, nA = a.n_act;
     constexpr int TX = kTXmax, MW = TX + 4;
+    const int mws = BAND ? R + 4 : MW;                       // row stride of the staged tile (R % 4 == 0)
     const int nAp = (nA + 3) & ~3, SS = nAp + 1;             // K padded to 4, s1 row stride odd (bank spread)
     const bool rows_given = a.pb.s1a != nullptr;             // Gy C already in HBM (k_dm_rows): no command image, no s1 here
     float* cimg = reinterpret_cast<float*>(lds_raw);         // [nA][nA]
@@ -495,7 +501,6 @@ __global__ void __launch_bounds__(256) k_phase_mfma4(const KArgs<float> a) {
     // (Gy C)[y0 + i][k] of the band from the operand-layout rows k_dm_rows wrote, ONCE for all its column chunks (as separate
     // 16 x 128 tile workgroups every chunk re-read them: a quarter of the kernel's HBM traffic at 81 actuators across):
     // ga_stride / 4 16-byte loads per lane (<= 8: n_act <= 128), all in flight together
-    constexpr int NQ = 8;
     f32x4 aq[NQ];
     const int nq = a.pb.ga_stride / 4;
     if (rows_given && !(a.ablate & 4)) {
@@ -503,6 +508,46 @@ __global__ void __launch_bounds__(256) k_phase_mfma4(const KArgs<float> a) {
         const f32x4* asrc = reinterpret_cast<const f32x4*>(a.pb.s1a) + ((size_t)e * (Rp >> 4) + (y0 >> 4)) * nq * 64 + lx;
 #pragma unroll
         for (int q4 = 0; q4 < NQ; ++q4) aq[q4] = asrc[q4 < nq ? 64 * q4 : 0];
+    }
+    // float4 number idx of a staged tile of `mw4` float4 per row whose element (r, c) is map[r0 + r][c0 + c] (rows of the map are only
+    // 4-byte aligned); rows < nr and columns < nc are needed, the rest stays zero
+    auto tile4 = [&](const float* map, const LayerTaps& tp, int S, int idx, int mw4, int nr, int nc, int r0, int c0) {
+        const int r = idx / mw4, c = 4 * (idx - r * mw4);
+        const int rr = r0 + r, cc = c0 + c;
+        const bool need = r < nr && c < nc && rr >= 0 && rr < S && cc >= 0 && cc < S;
+        int pr = rr + tp.oy, pc = cc + tp.ox;                   // torus: physical = (logical + origin) mod S
+        pr = pr >= S ? pr - S : pr;
+        pc = pc >= S ? pc - S : pc;
+        const bool ok = need && cc + 3 < S && pc + 3 < S;        // the 4 columns are contiguous in memory
+        f32x4 t;
+        __builtin_memcpy(&t, map + (ok ? (size_t)pr * S + pc : 0), 16);
+        f32x4 v = ok ? t : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (need && !ok) {
+            // a float4 that straddles the wrap of the torus or the edge of the screen: element by element
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                int pd = pc + d;
+                pd = pd >= S ? pd - S : pd;
+                if (cc + d < S) v[d] = map[(size_t)pr * S + pd];
+            }
+        }
+        return v;
+    };
+    if (BAND && a.pa.update_atm && !(a.ablate & 2)) {
+        const LayerTaps& tp = layer_taps(a.pa, 0, e);
+        const int S = a.pa.S_l[0], foot = a.pa.foot_l[0];
+        const float* map = static_cast<const float*>(a.pa.screen[0]) + (size_t)e * S * S;
+        const int r0 = y0 + foot + tp.dy - 1, c0 = foot + tp.dx - 1;
+        const int mw4 = mws / 4, total = (kTY + 3) * mw4;
+        for (int i0 = tid; i0 < total; i0 += 5 * 256) {           // 5 independent 16-byte loads in flight per lane, twice at R = 480
+            f32x4 v[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) v[k] = tile4(map, tp, S, i0 + 256 * k < total ? i0 + 256 * k : i0, mw4, tye + 3, R + 3, r0, c0);
+#pragma unroll
+            for (int k = 0; k < 5; ++k)
+                if (i0 + 256 * k < total) *reinterpret_cast<f32x4*>(mapt + 4 * (i0 + 256 * k)) = v[k];
+        }
+        __syncthreads();
     }
     for (int xb = 0; xb < (R + TX - 1) / TX; ++xb) {
     const int x0 = xb * TX, txe = min(TX, R - x0);
@@ -514,46 +559,27 @@ __global__ void __launch_bounds__(256) k_phase_mfma4(const KArgs<float> a) {
         for (int r = 0; r < 4; ++r) sup[tt][r] = 0.f;
 
     if (a.pa.update_atm && !(a.ablate & 2)) {
-        for (int l = 0; l < a.pa.n_layer; ++l) {
+        for (int l = 0; l < (BAND ? 1 : a.pa.n_layer); ++l) {
             const LayerTaps& tp = layer_taps(a.pa, l, e);
-            const int S = a.pa.S_l[l], foot = a.pa.foot_l[l];       // the layer's own grid (fov != 0: it grows with the altitude)
-            const float* map = static_cast<const float*>(a.pa.screen[l]) + (size_t)e * S * S;
-            const int r0 = y0 + foot + tp.dy - 1, c0 = x0 + foot + tp.dx - 1;
-            __syncthreads();                                  // the previous layer's tile is no longer read
-            {
-                // tile element (r, c) = map[r0 + r][c0 + c], staged as rows of MW / 4 float4 (the map rows are only 4-byte aligned)
+            if (!BAND) {
+                const int S = a.pa.S_l[l], foot = a.pa.foot_l[l];       // the layer's own grid (fov != 0: it grows with the altitude)
+                const float* map = static_cast<const float*>(a.pa.screen[l]) + (size_t)e * S * S;
+                const int r0 = y0 + foot + tp.dy - 1, c0 = x0 + foot + tp.dx - 1;
+                __syncthreads();                                  // the previous layer's tile is no longer read
                 constexpr int MW4 = MW / 4, NV4 = ((kTY + 3) * MW4 + 255) / 256;     // 3 independent 16-byte loads in flight per lane
                 f32x4 v[NV4];
 #pragma unroll
                 for (int k = 0; k < NV4; ++k) {
                     const int idx = tid + 256 * k;
-                    const int r = idx / MW4, c = 4 * (idx - r * MW4);
-                    const int rr = r0 + r, cc = c0 + c;
-                    const bool need = idx < (kTY + 3) * MW4 && r < tye + 3 && c < txe + 3 && rr >= 0 && rr < S && cc >= 0 && cc < S;
-                    int pr = rr + tp.oy, pc = cc + tp.ox;           // torus: physical = (logical + origin) mod S
-                    pr = pr >= S ? pr - S : pr;
-                    pc = pc >= S ? pc - S : pc;
-                    const bool ok = need && cc + 3 < S && pc + 3 < S;        // the 4 columns are contiguous in memory
-                    f32x4 t;
-                    __builtin_memcpy(&t, map + (ok ? (size_t)pr * S + pc : 0), 16);
-                    v[k] = ok ? t : f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (need && !ok) {
-                        // a float4 that straddles the wrap of the torus or the edge of the screen: element by element
-#pragma unroll
-                        for (int d = 0; d < 4; ++d) {
-                            int pd = pc + d;
-                            pd = pd >= S ? pd - S : pd;
-                            if (cc + d < S) v[k][d] = map[(size_t)pr * S + pd];
-                        }
-                    }
+                    v[k] = tile4(map, tp, S, idx < (kTY + 3) * MW4 ? idx : 0, MW4, idx < (kTY + 3) * MW4 ? tye + 3 : 0, txe + 3, r0, c0);
                 }
 #pragma unroll
                 for (int k = 0; k < NV4; ++k) {
                     const int idx = tid + 256 * k;
                     if (idx < (kTY + 3) * MW4) *reinterpret_cast<f32x4*>(mapt + 4 * idx) = v[k];
                 }
+                __syncthreads();
             }
-            __syncthreads();
             const float wx0 = (float)tp.wx[0], wx1 = (float)tp.wx[1], wx2 = (float)tp.wx[2], wx3 = (float)tp.wx[3];
             const float wy0 = (float)tp.wy[0], wy1 = (float)tp.wy[1], wy2 = (float)tp.wy[2], wy3 = (float)tp.wy[3];
             const float* mm = static_cast<const float*>(a.pa.minmax[l]) + 2 * e;
@@ -566,7 +592,7 @@ __global__ void __launch_bounds__(256) k_phase_mfma4(const KArgs<float> a) {
                 float h[4][4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float* m = mapt + (lc + q) * MW + xt;
+                    const float* m = mapt + (lc + q) * mws + xt + (BAND ? x0 : 0);
                     const f32x4 m0 = *reinterpret_cast<const f32x4*>(m), m1 = *reinterpret_cast<const f32x4*>(m + 4);
                     const float t[7] = {m0[0], m0[1], m0[2], m0[3], m1[0], m1[1], m1[2]};
 #pragma unroll
@@ -680,9 +706,19 @@ int launch_phase_mfma<float>(const KArgs<float>& a, int n_env, hipStream_t st) {
                                    (int)lds));
     dim3 grid(cdiv(a.R, TX), cdiv(a.R, kTY), n_env);
     if (a.R % 4 == 0 && !(a.ablate & 256)) {
-        if (lds > 64 * 1024)
-            AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_phase_mfma4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_phase_mfma4, dim3(1, grid.y, grid.z), dim3(256), lds, st, a);      // one workgroup per 16-row band
+        // one layer: its tile of the whole 16-row band in LDS (19 x (R + 4) floats) instead of one 19 x 132 tile per chunk
+        const size_t lds_band = sizeof(float) * ((a.pb.s1a ? 0 : (size_t)nA * nA + (size_t)kTY * (nAp + 1)) + (size_t)(kTY + 3) * (a.R + 4));
+        const bool band = a.pa.n_layer == 1 && a.pa.update_atm && lds_band <= 160 * 1024 && !(a.ablate & 512);
+        const size_t l4 = band ? lds_band : lds;
+        const int nq = a.pb.ga_stride / 4;
+        void (*kern)(const KArgs<float>);
+        if (nq <= 2) kern = band ? k_phase_mfma4<true, 2> : k_phase_mfma4<false, 2>;
+        else if (nq <= 4) kern = band ? k_phase_mfma4<true, 4> : k_phase_mfma4<false, 4>;
+        else if (nq <= 6) kern = band ? k_phase_mfma4<true, 6> : k_phase_mfma4<false, 6>;
+        else kern = band ? k_phase_mfma4<true, 8> : k_phase_mfma4<false, 8>;
+        if (l4 > 64 * 1024)
+            AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l4));
+        hipLaunchKernelGGL(kern, dim3(1, grid.y, grid.z), dim3(256), l4, st, a);      // one workgroup per 16-row band
     } else {
         hipLaunchKernelGGL(k_phase_mfma, grid, dim3(256), lds, st, a);
     }
