@@ -19,3 +19,13 @@ def test_fft528_factors_on_the_host(tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     print(out.stdout)
     assert out.returncode == 0 and "PASS" in out.stdout, out.stdout + out.stderr
+
+
+def test_lds_layouts_of_the_528_passes_are_conflict_free():
+    """The exchange layouts of pyr528_kernels.hip under the bank rules of MI355X_MICROARCH.md (scripts/lds_banks_528.py counts
+    LDS cycles per wave instruction): the column pass (16 columns per workgroup, as shipped) is conflict-free in both directions."""
+    out = subprocess.run(["python3", os.path.join(REPO, "scripts", "lds_banks_528.py")], capture_output=True, text=True, check=True).stdout
+    rows = {l.split()[0] + " " + l.split()[1]: [int(x) for x in l.split()[2:]] for l in out.splitlines() if l.startswith("P2/16")}
+    assert set(rows) == {"P2/16 fwd", "P2/16 inv"}
+    for name, (w, w_ideal, r, r_ideal) in rows.items():
+        assert w == w_ideal and r == r_ideal, (name, w, w_ideal, r, r_ideal)
