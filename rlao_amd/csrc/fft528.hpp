@@ -141,5 +141,91 @@ template <bool INV> __host__ __device__ inline void dft24(v2 (&v)[24]) {
     for (int i = 0; i < 24; ++i) v[i] = y[i];
 }
 
+
+// ---- 288 = 16 x 18 (the 20 x 20 Pyramid of the reference's Papyrus set-up) ------------------------------------------------------------
+// ---- 16 = 4 x 4 (Cooley-Tukey, inner twiddles W_16^(q0 r0)), in place, natural order ----
+template <bool INV> __host__ __device__ inline void dft16(v2 (&v)[16]) {
+    constexpr float c1 = 0.92387953251128673848f, s1 = 0.38268343236508978178f, c2 = 0.70710678118654752440f;
+#pragma unroll
+    for (int r0 = 0; r0 < 4; ++r0) dft4v<INV>(v[r0], v[4 + r0], v[8 + r0], v[12 + r0]);     // over r1: v[4 q0 + r0] = t[r0][q0]
+    // t[r0][q0] *= W_16^(q0 r0) = cos - i sin (forward), cos + i sin (inverse): exponents 1 2 3 / 2 4 6 / 3 6 9
+    auto rot = [](v2 x, float c, float sn) { return INV ? v2{x.x * c - x.y * sn, x.x * sn + x.y * c} : v2{x.x * c + x.y * sn, x.y * c - x.x * sn}; };
+    v[5] = rot(v[5], c1, s1);
+    v[6] = rot(v[6], c2, c2);
+    v[7] = rot(v[7], s1, c1);
+    v[9] = rot(v[9], c2, c2);
+    v[10] = rot90<INV>(v[10]);
+    v[11] = rot(v[11], -c2, c2);
+    v[13] = rot(v[13], s1, c1);
+    v[14] = rot(v[14], -c2, c2);
+    v[15] = rot(v[15], -c1, -s1);
+    v2 y[16];
+#pragma unroll
+    for (int q0 = 0; q0 < 4; ++q0) {
+        v2 a0 = v[4 * q0], a1 = v[4 * q0 + 1], a2 = v[4 * q0 + 2], a3 = v[4 * q0 + 3];         // over r0
+        dft4v<INV>(a0, a1, a2, a3);
+        y[q0] = a0;
+        y[q0 + 4] = a1;
+        y[q0 + 8] = a2;
+        y[q0 + 12] = a3;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = y[i];
+}
+// ---- 9 = 3 x 3 (Cooley-Tukey): n = 3 n1 + n2, k = k1 + 3 k2; on the elements v[P[i]], outputs to v[Q[k]] ----
+template <bool INV, int P0, int P1, int P2, int P3, int P4, int P5, int P6, int P7, int P8, int Q0, int Q1, int Q2, int Q3, int Q4, int Q5, int Q6, int Q7,
+          int Q8>
+__host__ __device__ inline void dft9(v2 (&v)[18]) {
+    constexpr int P[9] = {P0, P1, P2, P3, P4, P5, P6, P7, P8};
+    constexpr int Q[9] = {Q0, Q1, Q2, Q3, Q4, Q5, Q6, Q7, Q8};
+    // cos / sin of 2 pi p / 9, p = 1, 2, 4
+    constexpr float c1 = 0.76604444311897803520f, s1 = 0.64278760968653932632f, c2 = 0.17364817766693034885f, s2 = 0.98480775301220805937f,
+                    c4 = -0.93969262078590838405f, s4 = 0.34202014332566873304f;
+    v2 t[3][3];                                                    // t[n2][k1]
+#pragma unroll
+    for (int n2 = 0; n2 < 3; ++n2) {
+        v2 a = v[P[n2]], b = v[P[3 + n2]], c = v[P[6 + n2]];
+        dft3<INV>(a, b, c);
+        t[n2][0] = a;
+        t[n2][1] = b;
+        t[n2][2] = c;
+    }
+    auto rot = [](v2 x, float c, float sn) { return INV ? v2{x.x * c - x.y * sn, x.x * sn + x.y * c} : v2{x.x * c + x.y * sn, x.y * c - x.x * sn}; };
+    t[1][1] = rot(t[1][1], c1, s1);                                // W_9^(n2 k1)
+    t[1][2] = rot(t[1][2], c2, s2);
+    t[2][1] = rot(t[2][1], c2, s2);
+    t[2][2] = rot(t[2][2], c4, s4);
+#pragma unroll
+    for (int k1 = 0; k1 < 3; ++k1) {
+        v2 a = t[0][k1], b = t[1][k1], c = t[2][k1];
+        dft3<INV>(a, b, c);                                        // over n2 -> k2
+        v[Q[k1]] = a;
+        v[Q[k1 + 3]] = b;
+        v[Q[k1 + 6]] = c;
+    }
+}
+// ---- 18 = 2 x 9, prime-factor: n = (9 n1 + 2 n2) mod 18, k = (9 k1 + 10 k2) mod 18.  In place, natural order. ----
+template <bool INV> __host__ __device__ inline void dft18(v2 (&v)[18]) {
+#pragma unroll
+    for (int n2 = 0; n2 < 9; ++n2) {
+        const int p0 = (2 * n2) % 18, p1 = (9 + 2 * n2) % 18;
+        const v2 s = v[p0] + v[p1], d = v[p0] - v[p1];
+        v[p0] = s;                                                // k1 = 0
+        v[p1] = d;                                                // k1 = 1
+    }
+    // length 9 over n2 at (9 k1 + 2 n2) mod 18 -> k2 at (9 k1 + 10 k2) mod 18: the even slots for k1 = 0, the odd ones for k1 = 1
+    dft9<INV, 0, 2, 4, 6, 8, 10, 12, 14, 16, 0, 10, 2, 12, 4, 14, 6, 16, 8>(v);
+    dft9<INV, 9, 11, 13, 15, 17, 1, 3, 5, 7, 9, 1, 11, 3, 13, 5, 15, 7, 17>(v);
+}
+
+// the factor of length L in the registers of a lane
+template <int L, bool INV> __host__ __device__ inline void dft_len(v2 (&v)[L]) {
+    static_assert(L == 24 || L == 22 || L == 16 || L == 18, "no register-resident transform of this length");
+    if constexpr (L == 24) dft24<INV>(v);
+    else if constexpr (L == 22) dft22<INV>(v);
+    else if constexpr (L == 16) dft16<INV>(v);
+    else dft18<INV>(v);
+}
+
 }  // namespace f528
 }  // namespace ao

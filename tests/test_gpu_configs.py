@@ -294,14 +294,17 @@ def test_c2_geometry_1000_envs_ragged_shard():
 
 
 @pytest.mark.parametrize("n_sub,ppx,centering,modulation", [(40, 6, True, 0.0), (40, 6, True, 3.0), (7, 24, False, 2.0), (18, 12, True, 0.0),
-                                                            (29, 8, False, 0.0)])
+                                                            (29, 8, False, 0.0),
+                                                            (20, 6, True, 0.0), (20, 6, False, 3.0), (5, 16, False, 2.0), (8, 12, True, 0.0)])
 def test_c3_pyramid_528_register_passes_match_the_stockham_passes(n_sub, ppx, centering, modulation):
     """nRes = 528 in float32 runs the 24 x 22 register-resident transform (pyr528_kernels.hip); diagnostic option 99 bit 512
     puts the same shard back on the Stockham passes of pyr_kernels.hip (what float64 and every other length run, pinned to the
     reference by the golden replays).  Same field, same mask, different order of the float32 butterflies: frames agree to float32
     rounding of the brightest pixel.  Geometries: BASELINE configs[2] (R = 240: the specialised column pass, 4 camera rows per
     workgroup), and other ways to nRes = 528 -- 7 x 24 px (R = 168, 22-pixel camera: 2 camera rows per workgroup), 18 x 12 px (R = 216)
-    and 29 x 8 px (R = 232) -- with the mask centred on a pixel corner or on a pixel (fftshift between the transforms)."""
+    and 29 x 8 px (R = 232) -- with the mask centred on a pixel corner or on a pixel (fftshift between the transforms).  The last four
+    are nRes = 288 = 16 x 18, the same kernels on the other factor pair: the reference's Papyrus set-up (20 x 6 px, R = 120, with and
+    without modulation), 5 x 16 px (R = 80, an 18-pixel camera) and 8 x 12 px (R = 96: the general input range of the column pass)."""
     import torch
     from rlao_amd import _lib as L
     from rlao_amd.env import BatchedAOEnv
@@ -310,7 +313,7 @@ def test_c3_pyramid_528_register_passes_match_the_stockham_passes(n_sub, ppx, ce
     env = BatchedAOEnv(n_envs=4, device=0, dtype="f32", env_seed_stride=1)
     try:
         env.set_params(geo, camera="ideal", wfs_type="pyramid")
-        assert env._pyr_tables.nRes == 528 and env.R == n_sub * ppx
+        assert env._pyr_tables.nRes == (2 * n_sub + 8) * ppx and env._pyr_tables.nRes in (528, 288) and env.R == n_sub * ppx
         env.generate_new_phase_screen(5)
         env.dm.coefs = 0
         frames, signals = [], []
@@ -327,7 +330,7 @@ def test_c3_pyramid_528_register_passes_match_the_stockham_passes(n_sub, ppx, ce
         assert peak > 0 and np.isfinite(frames[0]).all()
         err = np.abs(frames[0] - frames[1]).max() / peak
         serr = np.abs(signals[0] - signals[1]).max() / np.abs(signals[1]).max()
-        print(f"528 passes vs Stockham, {n_sub} x {ppx} px, centering {centering}, modulation {modulation}: frame {err:.2e} of the peak, "
+        print(f"{env._pyr_tables.nRes} passes vs Stockham, {n_sub} x {ppx} px, centering {centering}, modulation {modulation}: frame {err:.2e} of the peak, "
               f"signal {serr:.2e} of the max")
         assert err < 2e-6 and serr < 2e-5, (err, serr)
     finally:
