@@ -1,4 +1,5 @@
-// 528-point transform of the 40x40 Pyramid (nRes = 528 = 24 x 22, BASELINE configs[2]) with register-resident factors.
+// 528-point transform of the 40x40 Pyramid (nRes = 528 = 24 x 22, BASELINE configs[2]) with register-resident factors; further down the
+// factors of 288 = 16 x 18 (the 20x20 Pyramid), used by the same kernels (pyr528_kernels.hip).
 //
 // The Stockham transform of fft.hpp moves every point through LDS once per radix (16, 3, 11) and spends three quarters of its
 // instructions on addresses, twiddle fetches and loop control.  Here a lane holds a whole factor:
