@@ -328,7 +328,7 @@ struct PyrArgs {
     int generic_fft;       // diagnostic (aoenv_set_option 99): bit 512 the Stockham passes also where pyr528_kernels.hip applies, bit 1024
                            // its column blocks dealt round-robin over the XCDs
 };
-// nRes = 528 in float32: the passes on the register-resident 24 x 22 transform (pyr528_kernels.hip)
+// nRes = 528 / 288 in float32: the passes on the register-resident 24 x 22 / 16 x 18 transforms (pyr528_kernels.hip)
 int pyramid528_supported(const PyrArgs<float>& a);
 int launch_pyramid528(const PyrArgs<float>& base, int n_theta, int chunk, hipStream_t st);
 // science-path PSF (Telescope.computePSF): |FFT2 of the zero-padded pupil field|^2 / N^2, fftshifted, into psf [E][N][N]
