@@ -240,3 +240,20 @@ def test_atmosphere_clock_source_matches_the_oracle(tmp_path):
                 w = np.array([O._cubic(f - k, *unit[j]) for j in range(4)])
                 np.testing.assert_allclose(got[i, col:col + 4], w, rtol=0, atol=2e-15)
         assert crossings >= int(n * np.abs(ratio).max()) - 1                      # at least the faster axis' pixel count
+
+
+def test_committed_counter_summaries_match_the_bench_workloads():
+    """bench.py reads `roofline.traffic` from the committed rocprofv3 --pmc summaries (profiles/r03_*_pmc.json): each must describe the
+    workload of its bench line (env count, camera) and name a production entry for every kernel of the line's dominant stage -- a
+    summary written with another camera key silently turns the traffic fields of a line into null."""
+    import bench
+    stage = {"C3": "pyramid", "C3M": "pyramid", "C4": "phase", "C5": "env_step"}
+    for name, cfg in bench.CONFIGS.items():
+        pmc = bench.load_pmc(cfg["envs"], name)
+        assert pmc is not None, name
+        total, parts = bench.pmc_traffic(pmc, stage[name])
+        assert total and total > 0 and len(parts) >= 1, (name, parts)
+        assert not pmc["entries_above_hbm_peak"], (name, pmc["entries_above_hbm_peak"])
+    for cam in ("papyrus", "ideal"):
+        pmc = bench.load_pmc(256, cam, cam)
+        assert pmc is not None and bench.pmc_traffic(pmc, "env_step")[0] > 0, cam
