@@ -1,6 +1,10 @@
-"""Per-wave timeline of the Pyramid column pass (diagnostic build with -DAO_PYR_STAMPS):
-     scripts/build_variant.sh pyrstamps pyr528_kernels -DAO_PYR_STAMPS   (or the commands in its header)
-     AOENV_LIB=build/pyrstamps/libaoenv.so python scripts/diag_pyr_stamps.py"""
+"""Per-wave timeline of the Pyramid column pass and the workgroups resident per CU (diagnostic build with -DAO_PYR_STAMPS):
+     cd rlao_amd/csrc && make && mkdir -p ../../build/pyrstamps &&
+       hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include -I. -DAO_PYR_STAMPS -c pyr528_kernels.hip -o ../../build/pyrstamps/pyr528_kernels.o &&
+       hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build/pyrstamps/libaoenv.so $(ls *.o | grep -v pyr528) ../../build/pyrstamps/pyr528_kernels.o
+     AOENV_LIB=build/pyrstamps/libaoenv.so python scripts/diag_pyr_stamps.py
+   The stamps perturb the kernel (s_memtime waits for the scalar unit): the column pass runs ~25 % slower in this build; the residency
+   per CU and the order of the phases are what it is for."""
 import ctypes as C, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
