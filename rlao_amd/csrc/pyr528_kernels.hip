@@ -1,23 +1,25 @@
-// Pyramid passes for nRes = 528 in float32 (the 40x40 Pyramid of BASELINE configs[2], OOPAO/Pyramid.py:469-607, 987-1006) on the
-// register-resident 24 x 22 transform of fft528.hpp -- and, the same kernels with the factor pair as a template parameter, for
-// nRes = 288 = 16 x 18 (the 20x20 Pyramid of the reference's Papyrus set-up).  The description below uses the numbers of 528.  Same three passes, same T1 / T2 layouts and the same arithmetic on the
-// pupil field as pyr_kernels.hip (which keeps every other length, float64 and the science PSF); what changes is how a
-// 528-point transform is carried out: a lane holds a whole 24- or 22-point factor, a sequence crosses LDS once per transform
-// (the Stockham version: three times), and global memory is read into and written from the registers that hold the factors.
+// Pyramid passes in float32 with register-resident transforms (OOPAO/Pyramid.py:469-607, 987-1006): nRes = 528 = 24 x 22, the 40x40
+// Pyramid of BASELINE configs[2], and -- the same kernels, the factor pair is a template parameter -- nRes = 288 = 16 x 18, the 20x20
+// Pyramid of the reference's Papyrus set-up (fft528.hpp holds the factors).  The numbers below are those of 528.
+// Same three passes, same T1 / T2 layouts and the same arithmetic on the pupil field as pyr_kernels.hip (which keeps every other
+// length, float64 and the science PSF); what changes is how a 528-point transform is carried out: a lane holds a whole 24- or
+// 22-point factor, a sequence crosses LDS once per transform (the Stockham version: three times), and global memory is read into
+// and written from the registers that hold the factors.
 //
-// A workgroup is 192 lanes = 8 sequences x 24 lanes: "role A" is (sequence, n2 or m1 < 22) -- 176 lanes, the 24-point factor --
-// and "role B" is (sequence, k1 < 24), the 22-point factor.
+// "Role A" lanes are (sequence, n2 or m1 < 22) and hold the 24-point factor, "role B" lanes are (sequence, k1 < 24) and hold the
+// 22-point factor; the row passes take 8 sequences per workgroup (192 lanes: 176 in role A), the column pass 16 (384 lanes).
 //   P1 rows     : the field of 8 pupil rows is built in LDS with the lanes along x; role A takes x = 22 n1 + n2 - off from there,
 //                 24-point DFT, twiddle, exchange; role B 22-point DFT and stores X[k1 + 24 k2]: 192 contiguous bytes per sequence
 //                 and store.
-//   P2 columns  : (16 sequences, 384 lanes) role A loads 16 neighbouring columns of T1 (one 128-byte line per row), 24-point DFT, twiddle, exchange; role B
+//   P2 columns  : role A loads 16 neighbouring columns of T1 (one 128-byte line per row), 24-point DFT, twiddle, exchange; role B
 //                 22-point DFT, fftshift (k2 -> k2 + 11: a renaming) and mask, inverse 22-point DFT, twiddle, exchange; role A
 //                 inverse 24-point DFT and stores T2.  Two exchanges for two transforms.
 //   P3 rows^-1  : role B loads rows of T2, inverse 22-point DFT, twiddle, exchange; role A inverse 24-point DFT, |.|^2, summed over
-//                 the rows of a camera row and the modulation points in LDS, binned to the camera row.
+//                 the rows of a camera row and the modulation points (in registers), binned to the camera row.
 // LDS layouts are chosen per pass so that the exchange is conflict-free for the lane order that keeps global accesses
 // contiguous (bank rules of ds_write_b64 / ds_read_b64, MI355X_MICROARCH.md; scripts/lds_banks_528.py counts them).
-// Measured at 1024 envs (C3, profiles/r03_C3_kernel_stats.csv): 395 + 975 + 535 us against 837 + 2827 + 1583 us for the Stockham passes.
+// Measured at 1024 envs: 528 (C3, profiles/r03_C3_kernel_stats.csv) 391 + 972 + 521 us against 837 + 2827 + 1583 us for the Stockham
+// passes; 288 (scripts/time_papyrus.py) 88 + 295 + 169 against 237 + 778 + 405 us.
 #include "common.hpp"
 #include "fft.hpp"
 #include "fft528.hpp"
