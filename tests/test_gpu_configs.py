@@ -72,6 +72,19 @@ def test_c3_pyramid_1024_envs_batch_invariance_and_determinism():
         env.close()
 
 
+def test_papyrus_pyramid_512_envs_batch_invariance_and_determinism():
+    """The reference's Papyrus set-up (OOPAOEnv.py): 8 m / 20x20 Pyramid, R = 120, FFT length 288 = 16 * 18 on the register-resident
+    passes: bitwise reruns, identical envs for identical seeds, distinct ones otherwise."""
+    from rlao_amd.env import BatchedAOEnv
+    env = BatchedAOEnv(n_envs=512, device=0, dtype="f32", env_seed_stride=0)
+    try:
+        env.set_params(dict(C3, nSubaperture=20), camera="ideal", wfs_type="pyramid")
+        assert env.R == 120 and env._pyr_tables.nRes == 288
+        _assert_batch_invariant(env, 4)
+    finally:
+        env.close()
+
+
 def test_c5_mcao_256_envs_distinct_seeds_match_oracle():
     """BASELINE configs[4] per-GPU shard: 256 envs, 3 layers, two chained DMs (21x21 + 11x11 actuators through the fused step
     kernel), every env its own seed; envs 0, 100 and 255 against the oracle (float64 NumPy, two DMs as a stacked command)."""
