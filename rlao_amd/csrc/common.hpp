@@ -146,6 +146,7 @@ struct MtAhead {
 };
 int launch_ring_gemm_draw_ahead(const float* X, const float* W, float* Cpart, int M, int N, int K, int splits, const MtAhead& m,
                                 hipStream_t st);
+int launch_sum_slabs(float* x, size_t n, int slabs, hipStream_t st);     // slab 0 += slabs 1 .. (in that order), n floats per slab
 int launch_gemm_nt_mfma(const float* X, const float* W, float* Cpart, int M, int N, int K, int ldx, int ldw, int splits,
                         hipStream_t st, int xsplits = 1, size_t xslab = 0);
 template <typename T>

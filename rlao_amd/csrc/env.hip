@@ -621,9 +621,17 @@ int recon_product(AoEnv* env, int* splits, hipStream_t st) {
                 const int s1 = gemm_splits(env->E, Kp, env->nSig);
                 AO_TRY(launch_gemm_nt_mfma(env->as<float>(env->signal), env->as<float>(env->fac_m), t, env->E, Kp, env->nSig, env->nSig,
                                            env->nSig, s1, st));
-                *splits = gemm_splits(env->E, env->A, Kp);
+                // (32 and more column tiles of 64 actuators fill the chip for any shard: no split of the short K, one output slab instead of
+                //  K / 64 of them -- at the ELT size 11 MB written and read back by the epilogue instead of 43; the choice does not depend on E)
+                *splits = (cdiv(env->A, 64) >= 32 && !(env->debug_ablate & 8192)) ? 1 : gemm_splits(env->E, env->A, Kp);
+                // a long chain read by many column tiles is summed once first (same order of the additions: same bits)
+                int xs = s1;
+                if (s1 > 1 && cdiv(env->A, 64) >= 8 && !(env->debug_ablate & 4096)) {
+                    AO_TRY(launch_sum_slabs(t, (size_t)env->E * Kp, s1, st));
+                    xs = 1;
+                }
                 return launch_gemm_nt_mfma(t, env->as<float>(env->fac_m2c), env->as<float>(env->vbuf), env->E, env->A, Kp, Kp, Kp, *splits,
-                                           st, s1, (size_t)env->E * Kp);
+                                           st, xs, (size_t)env->E * Kp);
             }
         }
         *splits = 1;

@@ -220,6 +220,29 @@ int gemm_splits(int M, int N, int K) {
     return smax > kMaxSplits ? kMaxSplits : smax;
 }
 
+// t[i] = slab 0 + slab 1 + ... (in that order: the order in which a chained product sums them while staging, gemm_nt_mfma_tile), in place
+// in slab 0.  A chained product re-sums the slabs in every workgroup that reads the tile -- 82 column tiles at the ELT size: 1 GB of L2
+// reads for 10 MB of slabs -- so a long chain is summed once, here, first.
+__global__ void __launch_bounds__(256) k_sum_slabs(float* __restrict__ x, int n4, int slabs, size_t slab4) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4* p = reinterpret_cast<float4*>(x);
+    float4 v[kMaxSplits];
+#pragma unroll
+    for (int z = 0; z < kMaxSplits; ++z) v[z] = p[(size_t)(z < slabs ? z : 0) * slab4 + i];
+    float4 a = v[0];
+#pragma unroll
+    for (int z = 1; z < kMaxSplits; ++z)
+        if (z < slabs) { a.x += v[z].x; a.y += v[z].y; a.z += v[z].z; a.w += v[z].w; }
+    p[i] = a;
+}
+int launch_sum_slabs(float* x, size_t n, int slabs, hipStream_t st) {
+    if (n % 4) return fail("sum_slabs: %zu elements per slab, not a multiple of 4", n);
+    hipLaunchKernelGGL(k_sum_slabs, dim3(cdiv((int)(n / 4), 256)), dim3(256), 0, st, x, (int)(n / 4), slabs, n / 4);
+    AO_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_gemm_nt_mfma(const float* X, const float* W, float* Cpart, int M, int N, int K, int ldx, int ldw, int splits,
                         hipStream_t st, int xsplits, size_t xslab) {
     const int kslice = cdiv(cdiv(K, splits), 32) * 32;
