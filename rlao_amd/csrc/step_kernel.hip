@@ -539,10 +539,15 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
     const int n_sig = 2 * n_valid, n4 = n_sig / 4, A = k.n_valid_act;
     const int km = tid >> 4, l16 = tid & 15;                     // (host: n_modes <= 52, nSig % 4 == 0, nSig <= 640)
     f32x4s mv[10];
-    {
+    // (a wave without a valid mode requests nothing: a load of a dummy address still takes its turn in the wave-instruction queue of the
+    //  vector-memory path, in front of the loads somebody waits for -- the 160 such loads of M and M2C^T cost the step 1.3 us)
+    if (4 * w < a.n_modes) {                                     // (wave-uniform: a wave holds the modes 4 w .. 4 w + 3)
         const f32x4s* row = reinterpret_cast<const f32x4s*>(a.fac_m + (size_t)(km < a.n_modes ? km : 0) * n_sig);
 #pragma unroll
         for (int j = 0; j < 10; ++j) mv[j] = row[(l16 + 16 * j < n4 ? l16 + 16 * j : 0) + late0];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 10; ++j) mv[j] = f32x4s{0.f, 0.f, 0.f, 0.f};
     }
     const float ref0 = a.sc.ref[ok ? s : 0], ref1 = a.sc.ref[ok ? n_valid + s : 0];
     // the integrator's inputs of this lane's actuator -- the previous observation (or the caller's action) and env.dm_prev
@@ -624,9 +629,14 @@ __global__ void __launch_bounds__(1024) k_env_step_sh6(const StepArgs a, const S
     f32x4s cv[13];
     int late1;
     asm volatile("v_mov_b32 %0, 0" : "=v"(late1) : "v"(late0));
+    if (16 * w < n_grp) {                                        // (wave-uniform: a wave holds the groups 16 w .. 16 w + 15)
 #pragma unroll
-    for (int j = 0; j < 13; ++j)
-        __builtin_memcpy(&cv[j], a.fac_m2c_t + (part + 4 * j < a.n_modes ? (size_t)(part + 4 * j) * A + 4 * (g_ok ? g : 0) : 0) + late1, 16);
+        for (int j = 0; j < 13; ++j)
+            __builtin_memcpy(&cv[j], a.fac_m2c_t + (part + 4 * j < a.n_modes ? (size_t)(part + 4 * j) * A + 4 * (g_ok ? g : 0) : 0) + late1, 16);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 13; ++j) cv[j] = f32x4s{0.f, 0.f, 0.f, 0.f};
+    }
     lds_barrier();
     AO_STAMP(19);
     double ss = 0.0;
